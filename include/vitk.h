@@ -1,0 +1,142 @@
+/*
+ * vitk.h — C ABI of libvitk.so: hand-written gfx950 (MI355X) HIP kernels for the ViT training step.
+ *
+ * The reference (TaiMingLu/vision_transformers_torch_xla) is 100 % Python and has no native/FFI surface;
+ * every entry point below therefore replaces an arithmetic call site of the reference's Python hot path
+ * (cited per function as file:line under /root/reference).  The Python boundary that callers see is
+ * create_model() / engine.train_one_epoch(); this header is what that host code binds through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing here allocates or frees memory
+ *   - bf16 tensors are raw uint16 bit patterns; fp32 are float; all row-major with explicit leading dims
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, no hidden syncs
+ *   - return 0 on success, negative VITK_E* otherwise; vitk_last_error() gives a thread-local message
+ *   - shapes are validated on the host before any launch; a rejected call launches nothing
+ */
+#ifndef VITK_H
+#define VITK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITK_VERSION 100
+
+#define VITK_OK 0
+#define VITK_EINVAL (-22)   /* bad shape / alignment / null pointer            */
+#define VITK_ENOSPC (-28)   /* workspace too small                             */
+#define VITK_ELAUNCH (-5)   /* hipGetLastError() reported a launch failure     */
+
+/* GEMM epilogues (vitk_gemm_nt) */
+enum {
+    VITK_EPI_PLAIN = 0,      /* out_bf16 = acc                                                        */
+    VITK_EPI_BIAS = 1,       /* out_bf16 = acc + bias[n]                                              */
+    VITK_EPI_BIAS_F32 = 2,   /* out_f32  = acc + bias[n]                                              */
+    VITK_EPI_BIAS_GELU = 3,  /* out_bf16 = h = acc + bias[n];  out2_bf16 = gelu_erf(h)                 */
+    VITK_EPI_BIAS_RES = 4,   /* out_bf16 = res[m,n] + rowscale[m / rows_per_group] * (acc + bias[n])   */
+    VITK_EPI_PATCH = 5,      /* out_bf16[(m/P)*(P+pre)+pre+m%P, n] = acc + bias[n] + pos[pre+m%P, n]   */
+    VITK_EPI_DGELU = 6       /* out_bf16 = acc * gelu_erf'(aux_bf16[m,n])                              */
+};
+
+int vitk_version(void);
+const char* vitk_last_error(void);
+
+/* ---- profiling of the dominant kernel family (GEMM): per-launch hipEvent brackets on the launch stream.
+ * No counterpart in the reference (it has no profiling hooks, engine.py:157-195 only keeps wall-clock deltas). */
+int vitk_prof_enable(int on);                                  /* 1: bracket every GEMM launch with events */
+int vitk_prof_read(double* total_ms, double* total_flop, int64_t* launches);  /* syncs the events, then resets */
+
+/* ---- LayerNorm.  Replaces timm LayerNorm = F.layer_norm(x,(D,),w,b,eps=1e-6) used at
+ * models/vision_transformer.py:148,163,530,616.  x,y bf16 [M,D]; gamma,beta fp32 [D]; mean,rstd fp32 [M]. D%8==0, D<=1024 */
+int vitk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                       int M, int D, float eps, void* stream);
+/* dx_bf16 = LN'(dy) (+ dres_bf16 if non-null).  dgamma/dbeta fp32 [D]: overwritten (accumulate=0) or added to.
+ * workspace: vitk_layernorm_bwd_workspace(M,D) bytes. */
+size_t vitk_layernorm_bwd_workspace(int M, int D);
+int vitk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate,
+                       int M, int D, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- GEMM, bf16 MFMA, fp32 accumulate.
+ * vitk_gemm_nt: C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue.  Replaces nn.Linear forward/dgrad inside timm
+ * Attention.qkv/.proj and Mlp.fc1/.fc2 (models/vision_transformer.py:149-159,164-171), the head (:618,990) and the
+ * PatchEmbed conv-as-GEMM (:552-560,936).  K%8==0, lda/ldb%8==0, N%4==0, ldc%4==0. */
+int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
+                 const float* bias, const void* res, int ldres, const float* rowscale, int rows_per_group,
+                 void* out2, int ldout2, const void* aux, int ldaux, const float* pos, int patches, int prefix,
+                 void* stream);
+/* vitk_gemm_tn: C[N,K] (fp32) = A[M,N]^T * B[M,K] (weight gradient, contraction over the M rows), split over M into
+ * slabs that a deterministic second kernel reduces; optionally also colsum(A) -> dbias[N].  accumulate: C += .
+ * N%8==0, K%8==0, lda/ldb%8==0, ldc%4==0.  workspace: vitk_gemm_tn_workspace(M,N,K). */
+size_t vitk_gemm_tn_workspace(int M, int N, int K);
+int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                 float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fused multi-head self-attention, head dim 64, no mask, no dropout.  Replaces timm Attention.forward's
+ * softmax(q k^T / sqrt(d)) v (F.scaled_dot_product_attention) reached from models/vision_transformer.py:176.
+ * qkv bf16 [B*N, 3*H*64] (columns: [q|k|v] x head x 64, exactly nn.Linear(D,3D)'s output), out bf16 [B*N, H*64],
+ * lse fp32 [B,H,N] = log sum exp of the scaled scores (saved for backward). */
+int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream);
+/* dqkv bf16 [B*N, 3*H*64] from dout, qkv, out, lse.  workspace (fp32 dq accumulator) only needed when N > 224. */
+size_t vitk_attention_bwd_workspace(int B, int N, int H);
+int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                       int B, int N, int H, float scale, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- patch embedding front end / pooling tail.
+ * im2col: NCHW fp32 image -> bf16 patch matrix [B*gh*gw, C*p*p], k = c*p*p + ky*p + kx, patch index gy*gw+gx
+ * (the Conv2d(k=s=p) + flatten(2).transpose(1,2) of timm PatchEmbed, models/vision_transformer.py:552-560,936). */
+int vitk_im2col_patches(const float* img, void* patches, int B, int C, int H, int W, int p, void* stream);
+/* x[b, t, :] = prefix_tokens[t, :] + pos[t, :] for t < prefix  (models/vision_transformer.py:761-778) */
+int vitk_prefix_tokens_fwd(const float* tokens, const float* pos, void* x, int B, int N, int D, int prefix, void* stream);
+/* dpos[t,:] (+)= sum_b dx[b,t,:] for all t;  dtokens[t,:] (+)= sum_b dx[b,t,:] for t<prefix */
+int vitk_pos_tokens_bwd(const void* dx, float* dpos, float* dtokens, int accumulate, int B, int N, int D, int prefix,
+                        void* stream);
+/* y[b,:] = mean_{t=first..N-1} x[b,t,:]  (global_pool_nlc 'avg', models/vision_transformer.py:431-433) */
+int vitk_pool_avg_fwd(const void* x, void* y, int B, int N, int D, int first, void* stream);
+/* dx[b,t,:] = dy[b,:]/(N-first) for t>=first else 0 */
+int vitk_pool_avg_bwd(const void* dy, void* dx, int B, int N, int D, int first, void* stream);
+/* gather / scatter of single token rows (pool 'token', models/vision_transformer.py:428-429; DeiT heads deit.py:108-119) */
+int vitk_gather_rows(const void* x, void* y, int B, int N, int D, int token, void* stream);
+int vitk_scatter_rows(const void* dy, void* dx, int B, int N, int D, int token, int zero_others, void* stream);
+
+/* ---- elementwise helpers */
+int vitk_rowscale(const void* x, const float* rowscale, int rows_per_group, void* y, int M, int D, void* stream);
+int vitk_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int vitk_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
+int vitk_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);
+int vitk_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+
+/* ---- losses on fp32 logits [B,C] with leading dim ld.  loss_rows fp32 [B] per-sample loss, dlogits fp32 [B,C]
+ * already scaled by grad_scale (= upstream grad / B for 'mean').
+ * Hard labels with label smoothing eps (eps=0: nn.CrossEntropyLoss; eps>0: timm LabelSmoothingCrossEntropy,
+ * main.py:926-935):  loss = (1-eps)*nll + eps*mean_c(-logp). */
+int vitk_xent_label_fwd_bwd(const float* logits, int ld, const int64_t* target, float smoothing, float* loss_rows,
+                            float* dlogits, int lddl, float grad_scale, int B, int C, void* stream);
+/* Soft targets (timm SoftTargetCrossEntropy): loss = sum_c -t*logp */
+int vitk_xent_soft_fwd_bwd(const float* logits, int ld, const float* target, int ldt, float* loss_rows,
+                           float* dlogits, int lddl, float grad_scale, int B, int C, void* stream);
+/* KD term T^2 * KL(softmax(t/T) || log_softmax(s/T)) per row ('batchmean' divides by B on the host side),
+ * main.py:939-970 / test_kd.py:43-88 */
+int vitk_kd_kl_fwd_bwd(const float* student, int lds_, const float* teacher, int ldt, float temperature,
+                       float* loss_rows, float* dstudent, int ldd, float grad_scale, int B, int C, void* stream);
+/* argmax over classes, first maximal index (torch.max semantics), engine.py:283 */
+int vitk_argmax_rows(const float* logits, int ld, int64_t* idx, int B, int C, void* stream);
+
+/* ---- fused AdamW over a flat fp32 parameter range (torch.optim.AdamW semantics, optim_factory.py:248-249),
+ * with bf16 copy-out of the updated weights and optional EMA (timm ModelEma, engine.py:198-202,273-274).
+ * p,g,m,v fp32 [n]; p_bf16 may be null; ema may be null. step is the 1-based step count. */
+int vitk_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, float* ema, float ema_decay,
+                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    float grad_scale, void* stream);
+/* sum of squares of a flat fp32 range -> out[0] (+)=, for clip_grad_norm_ (engine.py:175-177) */
+int vitk_sumsq(const float* g, int64_t n, float* out, int accumulate, void* workspace, size_t workspace_bytes,
+               void* stream);
+size_t vitk_sumsq_workspace(int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITK_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libvitk.so (declared in include/vitk.h).
+
+The library is the only compute path of this package: if it is missing, loading fails loudly with
+instructions to build it; there is no PyTorch/CPU fallback for any op.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libvitk.so"
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_i64 = C.c_int64
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/vitk.h one to one
+SIGNATURES = {
+    "vitk_version": (_i, []),
+    "vitk_last_error": (C.c_char_p, []),
+    "vitk_prof_enable": (_i, [_i]),
+    "vitk_prof_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "vitk_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "vitk_layernorm_bwd_workspace": (_sz, [_i, _i]),
+    "vitk_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "vitk_gemm_nt": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p]),
+    "vitk_gemm_tn_workspace": (_sz, [_i, _i, _i]),
+    "vitk_gemm_tn": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
+    "vitk_attention_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
+    "vitk_attention_bwd_workspace": (_sz, [_i, _i, _i]),
+    "vitk_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _sz, _p]),
+    "vitk_im2col_patches": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vitk_prefix_tokens_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vitk_pos_tokens_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vitk_pool_avg_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vitk_pool_avg_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vitk_gather_rows": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vitk_scatter_rows": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vitk_rowscale": (_i, [_p, _p, _i, _p, _i, _i, _p]),
+    "vitk_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
+    "vitk_cast_bf16_to_f32": (_i, [_p, _p, _i64, _p]),
+    "vitk_transpose_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "vitk_add_bf16": (_i, [_p, _p, _p, _i64, _p]),
+    "vitk_xent_label_fwd_bwd": (_i, [_p, _i, _p, _f, _p, _p, _i, _f, _i, _i, _p]),
+    "vitk_xent_soft_fwd_bwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _f, _i, _i, _p]),
+    "vitk_kd_kl_fwd_bwd": (_i, [_p, _i, _p, _i, _f, _p, _p, _i, _f, _i, _i, _p]),
+    "vitk_argmax_rows": (_i, [_p, _i, _p, _i, _i, _p]),
+    "vitk_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _f, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
+    "vitk_sumsq": (_i, [_p, _i64, _p, _i, _p, _sz, _p]),
+    "vitk_sumsq_workspace": (_sz, [_i64]),
+}
+
+EPI_PLAIN, EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_PATCH, EPI_DGELU = range(7)
+
+
+class VitkError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen libvitk.so and attach the prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise VitkError(
+            f"{LIB_PATH} not found: build the HIP kernels first "
+            "(python -m vision_transformers_torch_xla_amd.build, or __graft_entry__.build()). "
+            "There is no fallback implementation.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().vitk_last_error()
+        raise VitkError(f"{what or 'vitk call'} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,287 @@
+// HBM-bound helpers around the GEMM/attention core: patch gather (im2col), prefix tokens + position table,
+// token pooling, per-sample row scaling (stochastic depth), casts and the bf16 weight transpose.
+#include "common.h"
+
+#define EW_BLOCK 256
+static inline int ew_grid(size_t work_items) {
+    size_t g = (work_items + EW_BLOCK - 1) / EW_BLOCK;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// img NCHW fp32 -> patches bf16 [B*gh*gw, C*p*p]; one thread = 8 consecutive kx of one (patch, c, ky) row:
+// 32-byte contiguous fp32 read, 16-byte bf16 write.  p % 8 == 0.
+__global__ void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int C, int H, int W, int p) {
+    const int gh = H / p, gw = W / p;
+    const int kvec = C * p * p / 8;                       // 8-element vectors per patch row
+    const size_t total = (size_t)B * gh * gw * kvec;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int kv = (int)(i % kvec);
+        const size_t prow = i / kvec;
+        const int k = kv * 8;
+        const int c = k / (p * p), ky = (k / p) % p, kx = k % p;
+        const int gx = (int)(prow % gw), gy = (int)((prow / gw) % gh), b = (int)(prow / ((size_t)gw * gh));
+        const float* src = img + (((size_t)b * C + c) * H + (gy * p + ky)) * W + gx * p + kx;
+        const float4 a = *reinterpret_cast<const float4*>(src);
+        const float4 d = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+        store8(out + prow * (size_t)(kvec * 8) + k, v);
+    }
+}
+
+__global__ void prefix_tokens_kernel(const float* __restrict__ tokens, const float* __restrict__ pos, bf16_t* __restrict__ x,
+                                     int B, int N, int D, int prefix) {
+    const size_t total = (size_t)B * prefix * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int t = (int)((i / D) % prefix);
+        const int b = (int)(i / ((size_t)D * prefix));
+        x[((size_t)b * N + t) * D + d] = f2bf(tokens[(size_t)t * D + d] + pos[(size_t)t * D + d]);
+    }
+}
+
+// dpos[t][d] = sum_b dx[b][t][d]; one thread per (t, d-pair), loop over b (coalesced across d)
+__global__ void pos_tokens_bwd_kernel(const bf16_t* __restrict__ dx, float* __restrict__ dpos, float* __restrict__ dtok,
+                                      int accumulate, int B, int N, int D, int prefix) {
+    const size_t total = (size_t)N * (D / 2);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % (D / 2)) * 2;
+        const int t = (int)(i / (D / 2));
+        float s0 = 0.f, s1 = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(dx + ((size_t)b * N + t) * D + d);
+            s0 += __uint_as_float(w << 16);
+            s1 += __uint_as_float(w & 0xffff0000u);
+        }
+        float* pp = dpos + (size_t)t * D + d;
+        if (accumulate) { pp[0] += s0; pp[1] += s1; } else { pp[0] = s0; pp[1] = s1; }
+        if (t < prefix && dtok != nullptr) {
+            float* tp = dtok + (size_t)t * D + d;
+            if (accumulate) { tp[0] += s0; tp[1] += s1; } else { tp[0] = s0; tp[1] = s1; }
+        }
+    }
+}
+
+// y[b][d] = mean_{t>=first} x[b][t][d]; thread per (b, 8 columns)
+__global__ void pool_avg_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int N, int D, int first) {
+    const int nv = D / 8;
+    const size_t total = (size_t)B * nv;
+    const float inv = 1.0f / (float)(N - first);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv) * 8;
+        const int b = (int)(i / nv);
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = first; t < N; ++t) {
+            float v[8];
+            load8(x + ((size_t)b * N + t) * D + c, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] *= inv;
+        store8(y + (size_t)b * D + c, s);
+    }
+}
+
+__global__ void pool_avg_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int N, int D, int first) {
+    const int nv = D / 8;
+    const size_t total = (size_t)B * N * nv;
+    const float inv = 1.0f / (float)(N - first);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv) * 8;
+        const int t = (int)((i / nv) % N);
+        const int b = (int)(i / ((size_t)nv * N));
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t >= first) {
+            load8(dy + (size_t)b * D + c, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= inv;
+        }
+        store8(dx + ((size_t)b * N + t) * D + c, v);
+    }
+}
+
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int N, int D, int token) {
+    const int nv = D / 8;
+    const size_t total = (size_t)B * nv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv) * 8;
+        const int b = (int)(i / nv);
+        *reinterpret_cast<uint4*>(y + (size_t)b * D + c) = *reinterpret_cast<const uint4*>(x + ((size_t)b * N + token) * D + c);
+    }
+}
+
+// dx[b][token] = dy[b]; with zero_others every other row of dx is cleared
+__global__ void scatter_rows_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int N, int D, int token,
+                                    int zero_others) {
+    const int nv = D / 8;
+    const size_t total = zero_others ? (size_t)B * N * nv : (size_t)B * nv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv) * 8;
+        int t, b;
+        if (zero_others) { t = (int)((i / nv) % N); b = (int)(i / ((size_t)nv * N)); }
+        else { t = token; b = (int)(i / nv); }
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t == token) v = *reinterpret_cast<const uint4*>(dy + (size_t)b * D + c);
+        *reinterpret_cast<uint4*>(dx + ((size_t)b * N + t) * D + c) = v;
+    }
+}
+
+__global__ void rowscale_kernel(const bf16_t* __restrict__ x, const float* __restrict__ rowscale, int rows_per_group,
+                                bf16_t* __restrict__ y, int M, int D) {
+    const int nv = D / 8;
+    const size_t total = (size_t)M * nv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nv);
+        const float sc = rowscale[m / rows_per_group];
+        float v[8];
+        load8(x + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= sc;
+        store8(y + i * 8, v);
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+    const int64_t n8 = n / 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = *reinterpret_cast<const float4*>(src + i * 8);
+        const float4 b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        store8(dst + i * 8, v);
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) dst[i] = f2bf(src[i]);
+    }
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = bf2f(src[i]);
+}
+__global__ void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int64_t n) {
+    const int64_t n8 = n / 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float u[8], v[8];
+        load8(a + i * 8, u);
+        load8(b + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] += v[j];
+        store8(y + i * 8, u);
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += blockDim.x) y[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+    }
+}
+
+// dst[c][r] = src[r][c], 64x64 tiles through LDS (padded), 256 threads
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int gr = r0 + r, gc = c0 + tx;
+        tile[r][tx] = (gr < rows && gc < cols) ? src[(size_t)gr * cols + gc] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        const int gc = c0 + c, gr = r0 + tx;
+        if (gc < cols && gr < rows) dst[(size_t)gc * rows + gr] = tile[tx][c];
+    }
+}
+
+extern "C" {
+
+int vitk_im2col_patches(const float* img, void* patches, int B, int C, int H, int W, int p, void* stream) {
+    VITK_REQUIRE(img && patches, "im2col: null pointer");
+    VITK_REQUIRE(B > 0 && C > 0 && p > 0 && p % 8 == 0 && H % p == 0 && W % p == 0,
+                 "im2col: need p%%8==0 and H,W multiples of p (B=%d C=%d H=%d W=%d p=%d)", B, C, H, W, p);
+    VITK_REQUIRE(vitk_aligned(img, 16) && vitk_aligned(patches, 16), "im2col: pointers must be 16-byte aligned");
+    const size_t total = (size_t)B * (H / p) * (W / p) * (C * p * p / 8);
+    im2col_kernel<<<ew_grid(total), EW_BLOCK, 0, (hipStream_t)stream>>>(img, (bf16_t*)patches, B, C, H, W, p);
+    return vitk_check_launch("im2col");
+}
+
+int vitk_prefix_tokens_fwd(const float* tokens, const float* pos, void* x, int B, int N, int D, int prefix, void* stream) {
+    VITK_REQUIRE(tokens && pos && x, "prefix_tokens_fwd: null pointer");
+    VITK_REQUIRE(B > 0 && N > 0 && D > 0 && prefix > 0 && prefix <= N, "prefix_tokens_fwd: bad shape");
+    prefix_tokens_kernel<<<ew_grid((size_t)B * prefix * D), EW_BLOCK, 0, (hipStream_t)stream>>>(tokens, pos, (bf16_t*)x, B, N, D, prefix);
+    return vitk_check_launch("prefix_tokens_fwd");
+}
+
+int vitk_pos_tokens_bwd(const void* dx, float* dpos, float* dtokens, int accumulate, int B, int N, int D, int prefix, void* stream) {
+    VITK_REQUIRE(dx && dpos, "pos_tokens_bwd: null pointer");
+    VITK_REQUIRE(B > 0 && N > 0 && D > 0 && D % 2 == 0 && prefix >= 0 && prefix <= N, "pos_tokens_bwd: bad shape");
+    pos_tokens_bwd_kernel<<<ew_grid((size_t)N * D / 2), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)dx, dpos, dtokens, accumulate, B, N, D, prefix);
+    return vitk_check_launch("pos_tokens_bwd");
+}
+
+int vitk_pool_avg_fwd(const void* x, void* y, int B, int N, int D, int first, void* stream) {
+    VITK_REQUIRE(x && y, "pool_avg_fwd: null pointer");
+    VITK_REQUIRE(B > 0 && N > first && first >= 0 && D % 8 == 0, "pool_avg_fwd: bad shape");
+    VITK_REQUIRE(vitk_aligned(x, 16) && vitk_aligned(y, 16), "pool_avg_fwd: pointers must be 16-byte aligned");
+    pool_avg_fwd_kernel<<<ew_grid((size_t)B * D / 8), 64, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, B, N, D, first);
+    return vitk_check_launch("pool_avg_fwd");
+}
+
+int vitk_pool_avg_bwd(const void* dy, void* dx, int B, int N, int D, int first, void* stream) {
+    VITK_REQUIRE(dy && dx, "pool_avg_bwd: null pointer");
+    VITK_REQUIRE(B > 0 && N > first && first >= 0 && D % 8 == 0, "pool_avg_bwd: bad shape");
+    VITK_REQUIRE(vitk_aligned(dy, 16) && vitk_aligned(dx, 16), "pool_avg_bwd: pointers must be 16-byte aligned");
+    pool_avg_bwd_kernel<<<ew_grid((size_t)B * N * D / 8), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)dy, (bf16_t*)dx, B, N, D, first);
+    return vitk_check_launch("pool_avg_bwd");
+}
+
+int vitk_gather_rows(const void* x, void* y, int B, int N, int D, int token, void* stream) {
+    VITK_REQUIRE(x && y, "gather_rows: null pointer");
+    VITK_REQUIRE(B > 0 && N > 0 && token >= 0 && token < N && D % 8 == 0, "gather_rows: bad shape");
+    VITK_REQUIRE(vitk_aligned(x, 16) && vitk_aligned(y, 16), "gather_rows: pointers must be 16-byte aligned");
+    gather_rows_kernel<<<ew_grid((size_t)B * D / 8), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, B, N, D, token);
+    return vitk_check_launch("gather_rows");
+}
+
+int vitk_scatter_rows(const void* dy, void* dx, int B, int N, int D, int token, int zero_others, void* stream) {
+    VITK_REQUIRE(dy && dx, "scatter_rows: null pointer");
+    VITK_REQUIRE(B > 0 && N > 0 && token >= 0 && token < N && D % 8 == 0, "scatter_rows: bad shape");
+    VITK_REQUIRE(vitk_aligned(dy, 16) && vitk_aligned(dx, 16), "scatter_rows: pointers must be 16-byte aligned");
+    const size_t total = zero_others ? (size_t)B * N * D / 8 : (size_t)B * D / 8;
+    scatter_rows_kernel<<<ew_grid(total), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)dy, (bf16_t*)dx, B, N, D, token, zero_others);
+    return vitk_check_launch("scatter_rows");
+}
+
+int vitk_rowscale(const void* x, const float* rowscale, int rows_per_group, void* y, int M, int D, void* stream) {
+    VITK_REQUIRE(x && rowscale && y, "rowscale: null pointer");
+    VITK_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && rows_per_group > 0, "rowscale: bad shape");
+    VITK_REQUIRE(vitk_aligned(x, 16) && vitk_aligned(y, 16), "rowscale: pointers must be 16-byte aligned");
+    rowscale_kernel<<<ew_grid((size_t)M * D / 8), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)x, rowscale, rows_per_group, (bf16_t*)y, M, D);
+    return vitk_check_launch("rowscale");
+}
+
+int vitk_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    VITK_REQUIRE(src && dst && n > 0, "cast_f32_to_bf16: bad arguments");
+    VITK_REQUIRE(vitk_aligned(src, 16) && vitk_aligned(dst, 16), "cast_f32_to_bf16: pointers must be 16-byte aligned");
+    cast_f32_bf16_kernel<<<ew_grid((size_t)(n / 8 + 1)), EW_BLOCK, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, n);
+    return vitk_check_launch("cast_f32_to_bf16");
+}
+
+int vitk_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream) {
+    VITK_REQUIRE(src && dst && n > 0, "cast_bf16_to_f32: bad arguments");
+    cast_bf16_f32_kernel<<<ew_grid((size_t)n), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)src, dst, n);
+    return vitk_check_launch("cast_bf16_to_f32");
+}
+
+int vitk_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream) {
+    VITK_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose_bf16: bad arguments");
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    transpose_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, (bf16_t*)dst, rows, cols);
+    return vitk_check_launch("transpose_bf16");
+}
+
+int vitk_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream) {
+    VITK_REQUIRE(a && b && y && n > 0, "add_bf16: bad arguments");
+    VITK_REQUIRE(vitk_aligned(a, 16) && vitk_aligned(b, 16) && vitk_aligned(y, 16), "add_bf16: pointers must be 16-byte aligned");
+    add_bf16_kernel<<<ew_grid((size_t)(n / 8 + 1)), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
+    return vitk_check_launch("add_bf16");
+}
+
+}  // extern "C"

@@ -1,0 +1,473 @@
+// bf16 MFMA GEMMs (fp32 accumulate) for the ViT linears, gfx950.
+//
+//   gemm_nt : C[M,N] = A[M,K] * B[N,K]^T   (forward linears, data gradients with a transposed weight copy)
+//   gemm_tn : C[N,K] = A[M,N]^T * B[M,K]   (weight gradients: contraction over the M token rows, split over M)
+//
+// Both use v_mfma_f32_16x16x32_bf16 on a 128x128 block tile, 4 waves (2x2), each wave a 64x64 sub-tile
+// (4x4 MFMA tiles, 64 accumulator registers).  Operands are staged global -> registers -> LDS; the next
+// K-step's global loads are issued before the MFMAs of the current one.
+//   gemm_nt keeps K contiguous in LDS ([row][64] with a 16-byte-chunk XOR swizzle, conflict-free
+//   ds_read_b128 fragments).  gemm_tn keeps the output dimension contiguous ([m][128]) and builds the
+//   fragments with the transposing read ds_read_b64_tr_b16.
+// The MFMA operands are swapped (first operand = the matrix whose rows become output columns) so that each
+// lane ends up holding 4 consecutive output columns of one row: 8-byte (bf16) / 16-byte (fp32) stores.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+bool vitk_prof_begin(void* stream, double flop);
+void vitk_prof_end(void* stream);
+
+#define GBM 128
+#define GBN 128
+#define GBK 64
+
+struct GemmNTParams {
+    const bf16_t* A; int lda;
+    const bf16_t* B; int ldb;
+    void* C; int ldc;
+    int M, N, K;
+    const float* bias;
+    const bf16_t* res; int ldres;
+    const float* rowscale; int rows_per_group;
+    bf16_t* out2; int ldout2;
+    const bf16_t* aux; int ldaux;
+    const float* pos; int patches; int prefix;
+    int tiles_n; int num_tiles;
+};
+
+// Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Remap so that every XCD works on a
+// contiguous range of logical tiles (neighbouring tiles share the A row panel); bijective for any grid size.
+static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static __device__ __forceinline__ void store4_bf16(bf16_t* p, const float (&v)[4]) {
+    uint2 r;
+    r.x = pack2bf(v[0], v[1]);
+    r.y = pack2bf(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = r;
+}
+static __device__ __forceinline__ void load4_bf16(const bf16_t* p, float (&v)[4]) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[GBM * GBK];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[GBN * GBK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const int tile = xcd_remap(blockIdx.x, p.num_tiles);
+    const int m0 = (tile / p.tiles_n) * GBM;
+    const int n0 = (tile % p.tiles_n) * GBN;
+
+    // staging: thread handles 16-byte chunks ci = tid + 256*i ; row = ci/8, chunk = ci%8
+    const int srow = tid >> 3, sch = tid & 7;
+    const bf16_t* gA[4];
+    const bf16_t* gB[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow + 32 * i;
+        int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+        gA[i] = p.A + (size_t)gm * p.lda + sch * 8;
+        gB[i] = p.B + (size_t)gn * p.ldb + sch * 8;
+        soff[i] = row * GBK + ((sch ^ (row & 7)) << 3);
+    }
+    u32x4 ra[4], rb[4];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + GBK - 1) / GBK;
+    // loads are unconditional (clamped address) and zeroed by a value select, which keeps ra/rb in registers
+    {
+        const bool kin = sch * 8 < p.K;
+        const int ko = kin ? 0 : -(sch * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 ta = *reinterpret_cast<const u32x4*>(gA[i] + ko);
+            const u32x4 tb = *reinterpret_cast<const u32x4*>(gB[i] + ko);
+            ra[i] = kin ? ta : zero4;
+            rb[i] = kin ? tb : zero4;
+        }
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(&sA[soff[i]]) = ra[i];
+            *reinterpret_cast<u32x4*>(&sB[soff[i]]) = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            const int kofs = (kt + 1) * GBK;
+            const bool kin = kofs + sch * 8 < p.K;
+            const int ko = kin ? kofs : -(sch * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 ta = *reinterpret_cast<const u32x4*>(gA[i] + ko);
+                const u32x4 tb = *reinterpret_cast<const u32x4*>(gB[i] + ko);
+                ra[i] = kin ? ta : zero4;
+                rb[i] = kin ? tb : zero4;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+            const int ch = ks * 4 + lg;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rowA = wm * 64 + t * 16 + lr;
+                const int rowB = wn * 64 + t * 16 + lr;
+                fa[t] = *reinterpret_cast<const bf16x8*>(&sA[rowA * GBK + ((ch ^ (rowA & 7)) << 3)]);
+                fb[t] = *reinterpret_cast<const bf16x8*>(&sB[rowB * GBK + ((ch ^ (rowB & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[tm][tn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = 4*(lane>>4)
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + wm * 64 + tm * 16 + lr;
+        if (m >= p.M) continue;
+        float rs = 1.0f;
+        int orow = m;
+        const float* posrow = nullptr;
+        if (EPI == VITK_EPI_BIAS_RES) {
+            if (p.rowscale != nullptr) rs = p.rowscale[m / p.rows_per_group];
+        }
+        if (EPI == VITK_EPI_PATCH) {
+            const int b = m / p.patches, pi = m - b * p.patches;
+            orow = b * (p.patches + p.prefix) + p.prefix + pi;
+            posrow = p.pos + (size_t)(p.prefix + pi) * p.N;
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wn * 64 + tn * 16 + 4 * lg;
+            if (n >= p.N) continue;
+            float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
+            if (EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU) {
+                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            }
+            if (EPI == VITK_EPI_PLAIN || EPI == VITK_EPI_BIAS) {
+                store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+            } else if (EPI == VITK_EPI_BIAS_F32) {
+                *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (EPI == VITK_EPI_BIAS_GELU) {
+                float a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = gelu_erf(bf2f(f2bf(v[j])));
+                store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+                store4_bf16(p.out2 + (size_t)m * p.ldout2 + n, a);
+            } else if (EPI == VITK_EPI_BIAS_RES) {
+                float r[4];
+                load4_bf16(p.res + (size_t)m * p.ldres + n, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = r[j] + rs * v[j];
+                store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+            } else if (EPI == VITK_EPI_PATCH) {
+                const float4 q4 = *reinterpret_cast<const float4*>(posrow + n);
+                v[0] += q4.x; v[1] += q4.y; v[2] += q4.z; v[3] += q4.w;
+                store4_bf16((bf16_t*)p.C + (size_t)orow * p.ldc + n, v);
+            } else if (EPI == VITK_EPI_DGELU) {
+                float h[4];
+                load4_bf16(p.aux + (size_t)m * p.ldaux + n, h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= dgelu_erf(h[j]);
+                store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct GemmTNParams {
+    const bf16_t* A; int lda;
+    const bf16_t* B; int ldb;
+    float* slab;        // [splits][N][K]
+    float* colslab;     // [splits][N] or null
+    int M, N, K;
+    int m_per_split;
+    int tiles_k;
+};
+
+#define TBM 64   // contraction rows staged per step
+
+static __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* lo, const bf16_t* hi) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)lo);
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)hi);
+    return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+template <bool COLSUM>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[TBM * GBN];   // [m][n]
+    __shared__ __attribute__((aligned(16))) bf16_t sB[TBM * GBN];   // [m][k]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;    // wave's 64 n-rows / 64 k-cols of the output tile
+    const int lr = lane & 15, lg = lane >> 4;
+    const int lq = lr >> 2, lp = lr & 3;
+
+    const int n0 = (blockIdx.x / p.tiles_k) * GBN;
+    const int k0 = (blockIdx.x % p.tiles_k) * GBN;
+    const int split = blockIdx.y;
+    const int ms = split * p.m_per_split;
+    int me = ms + p.m_per_split; me = me < p.M ? me : p.M;
+
+    // staging: chunk ci = tid + 256*i ; row = ci/16 (0..63), chunk = ci%16 (8 columns each)
+    const int srow = tid >> 4, sch = tid & 15;
+    const bool a_col_ok = n0 + sch * 8 < p.N;
+    const bool b_col_ok = k0 + sch * 8 < p.K;
+    const bf16_t* gA = p.A + (size_t)(a_col_ok ? n0 + sch * 8 : 0);
+    const bf16_t* gB = p.B + (size_t)(b_col_ok ? k0 + sch * 8 : 0);
+    u32x4 ra[4], rb[4];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    float colacc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) colacc[j] = 0.f;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bool do_colsum = COLSUM && (blockIdx.x % p.tiles_k) == 0;
+
+    auto gload = [&](int mbase) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = mbase + srow + 16 * i;
+            const bool ok = gm < me;
+            const int gmc = ok ? gm : p.M - 1;      // unconditional load from a valid row, zeroed by value select
+            const u32x4 ta = *reinterpret_cast<const u32x4*>(gA + (size_t)gmc * p.lda);
+            const u32x4 tb = *reinterpret_cast<const u32x4*>(gB + (size_t)gmc * p.ldb);
+            ra[i] = (ok && a_col_ok) ? ta : zero4;
+            rb[i] = (ok && b_col_ok) ? tb : zero4;
+        }
+    };
+
+    gload(ms);
+    for (int mb = ms; mb < me; mb += TBM) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 16 * i;
+            *reinterpret_cast<u32x4*>(&sA[row * GBN + sch * 8]) = ra[i];
+            *reinterpret_cast<u32x4*>(&sB[row * GBN + sch * 8]) = rb[i];
+            if (do_colsum) {
+                const u32x4 r = ra[i];
+                colacc[0] += __uint_as_float(r.x << 16); colacc[1] += __uint_as_float(r.x & 0xffff0000u);
+                colacc[2] += __uint_as_float(r.y << 16); colacc[3] += __uint_as_float(r.y & 0xffff0000u);
+                colacc[4] += __uint_as_float(r.z << 16); colacc[5] += __uint_as_float(r.z & 0xffff0000u);
+                colacc[6] += __uint_as_float(r.w << 16); colacc[7] += __uint_as_float(r.w & 0xffff0000u);
+            }
+        }
+        __syncthreads();
+        if (mb + TBM < me) gload(mb + TBM);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+            const int r0 = ks * 32 + 8 * lg + lq;   // rows of the first 4-row block; second block is +4
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ca = wr * 64 + t * 16 + 4 * lp;
+                const int cb = wc * 64 + t * 16 + 4 * lp;
+                fa[t] = tr_frag(&sA[r0 * GBN + ca], &sA[(r0 + 4) * GBN + ca]);
+                fb[t] = tr_frag(&sB[r0 * GBN + cb], &sB[(r0 + 4) * GBN + cb]);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk)
+                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tk], fa[tn], acc[tn][tk], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* slab = p.slab + (size_t)split * p.N * p.K;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int n = n0 + wr * 64 + tn * 16 + lr;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk) {
+            const int k = k0 + wc * 64 + tk * 16 + 4 * lg;
+            if (k >= p.K) continue;
+            *reinterpret_cast<float4*>(slab + (size_t)n * p.K + k) =
+                make_float4(acc[tn][tk][0], acc[tn][tk][1], acc[tn][tk][2], acc[tn][tk][3]);
+        }
+    }
+    if (do_colsum) {
+        // fold the 16 row groups (tid>>4) that share a column chunk; reuse sA as fp32 scratch [16][128]
+        float* red = reinterpret_cast<float*>(sA);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[srow * GBN + sch * 8 + j] = colacc[j];
+        __syncthreads();
+        if (tid < GBN && n0 + tid < p.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r * GBN + tid];
+            p.colslab[(size_t)split * p.N + n0 + tid] = s;
+        }
+    }
+}
+
+// out[r*ldo + c] = (accumulate ? out : 0) + sum_s slab[s][r][c], fixed order; cols % 4 == 0
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, int splits, int rows, int cols, float* __restrict__ out,
+                                    int ldo, int accumulate) {
+    const size_t total4 = (size_t)rows * cols / 4;
+    const size_t stride = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        float4 s = *reinterpret_cast<const float4*>(slab + e);
+        for (int k = 1; k < splits; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(slab + k * stride + e);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const int r = (int)(e / cols), c = (int)(e % cols);
+        float4* dst = reinterpret_cast<float4*>(out + (size_t)r * ldo + c);
+        if (accumulate) { const float4 o = *dst; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        *dst = s;
+    }
+}
+__global__ void reduce_vec_kernel(const float* __restrict__ slab, int splits, int n, float* __restrict__ out, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+static int tn_splits(int M, int N, int K) {
+    const int tiles = ((N + GBN - 1) / GBN) * ((K + GBN - 1) / GBN);
+    int s = (1024 + tiles - 1) / tiles;
+    const int max_by_rows = (M + 511) / 512;   // at least 512 contraction rows per split
+    if (s > max_by_rows) s = max_by_rows;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return s;
+}
+
+extern "C" {
+
+int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
+                 const float* bias, const void* res, int ldres, const float* rowscale, int rows_per_group, void* out2,
+                 int ldout2, const void* aux, int ldaux, const float* pos, int patches, int prefix, void* stream) {
+    VITK_REQUIRE(A && B && C, "gemm_nt: null operand");
+    VITK_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
+    VITK_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K,
+                 "gemm_nt: K, lda, ldb must be multiples of 8 and lda,ldb >= K (K=%d lda=%d ldb=%d)", K, lda, ldb);
+    VITK_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm_nt: N and ldc must be multiples of 4, ldc >= N (N=%d ldc=%d)", N, ldc);
+    VITK_REQUIRE(vitk_aligned(A, 16) && vitk_aligned(B, 16) && vitk_aligned(C, 16), "gemm_nt: operands must be 16-byte aligned");
+    VITK_REQUIRE(epilogue >= VITK_EPI_PLAIN && epilogue <= VITK_EPI_DGELU, "gemm_nt: unknown epilogue %d", epilogue);
+    if (epilogue != VITK_EPI_PLAIN && epilogue != VITK_EPI_DGELU)
+        VITK_REQUIRE(bias && vitk_aligned(bias, 16), "gemm_nt: epilogue %d needs a 16-byte aligned bias", epilogue);
+    if (epilogue == VITK_EPI_BIAS_GELU)
+        VITK_REQUIRE(out2 && ldout2 % 4 == 0 && ldout2 >= N && vitk_aligned(out2, 16), "gemm_nt: BIAS_GELU needs out2 (ld%%4==0)");
+    if (epilogue == VITK_EPI_BIAS_RES) {
+        VITK_REQUIRE(res && ldres % 4 == 0 && ldres >= N && vitk_aligned(res, 16), "gemm_nt: BIAS_RES needs res (ld%%4==0)");
+        VITK_REQUIRE(!rowscale || rows_per_group > 0, "gemm_nt: rowscale needs rows_per_group > 0");
+    }
+    if (epilogue == VITK_EPI_DGELU)
+        VITK_REQUIRE(aux && ldaux % 4 == 0 && ldaux >= N && vitk_aligned(aux, 16), "gemm_nt: DGELU needs aux (ld%%4==0)");
+    if (epilogue == VITK_EPI_PATCH)
+        VITK_REQUIRE(pos && patches > 0 && prefix >= 0 && M % patches == 0 && vitk_aligned(pos, 16),
+                     "gemm_nt: PATCH needs pos, patches>0, M%%patches==0 (M=%d patches=%d)", M, patches);
+
+    GemmNTParams p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16_t*)res; p.ldres = ldres;
+    p.rowscale = rowscale; p.rows_per_group = rows_per_group; p.out2 = (bf16_t*)out2; p.ldout2 = ldout2;
+    p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pos = pos; p.patches = patches; p.prefix = prefix;
+    const int tiles_m = (M + GBM - 1) / GBM;
+    p.tiles_n = (N + GBN - 1) / GBN;
+    p.num_tiles = tiles_m * p.tiles_n;
+    hipStream_t s = (hipStream_t)stream;
+    const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K);
+    switch (epilogue) {
+        case VITK_EPI_PLAIN: gemm_nt_kernel<VITK_EPI_PLAIN><<<p.num_tiles, 256, 0, s>>>(p); break;
+        case VITK_EPI_BIAS: gemm_nt_kernel<VITK_EPI_BIAS><<<p.num_tiles, 256, 0, s>>>(p); break;
+        case VITK_EPI_BIAS_F32: gemm_nt_kernel<VITK_EPI_BIAS_F32><<<p.num_tiles, 256, 0, s>>>(p); break;
+        case VITK_EPI_BIAS_GELU: gemm_nt_kernel<VITK_EPI_BIAS_GELU><<<p.num_tiles, 256, 0, s>>>(p); break;
+        case VITK_EPI_BIAS_RES: gemm_nt_kernel<VITK_EPI_BIAS_RES><<<p.num_tiles, 256, 0, s>>>(p); break;
+        case VITK_EPI_PATCH: gemm_nt_kernel<VITK_EPI_PATCH><<<p.num_tiles, 256, 0, s>>>(p); break;
+        case VITK_EPI_DGELU: gemm_nt_kernel<VITK_EPI_DGELU><<<p.num_tiles, 256, 0, s>>>(p); break;
+    }
+    if (pr) vitk_prof_end(stream);
+    return vitk_check_launch("gemm_nt");
+}
+
+size_t vitk_gemm_tn_workspace(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int s = tn_splits(M, N, K);
+    return (size_t)s * ((size_t)N * K + (size_t)N) * sizeof(float);
+}
+
+int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K, float* dbias,
+                 int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    VITK_REQUIRE(A && B && C && workspace, "gemm_tn: null operand");
+    VITK_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
+    VITK_REQUIRE(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= N && ldb >= K,
+                 "gemm_tn: N, K, lda, ldb must be multiples of 8 (N=%d K=%d lda=%d ldb=%d)", N, K, lda, ldb);
+    VITK_REQUIRE(ldc % 4 == 0 && ldc >= K, "gemm_tn: ldc must be a multiple of 4 and >= K");
+    VITK_REQUIRE(vitk_aligned(A, 16) && vitk_aligned(B, 16) && vitk_aligned(C, 16) && vitk_aligned(workspace, 16),
+                 "gemm_tn: operands must be 16-byte aligned");
+    if (workspace_bytes < vitk_gemm_tn_workspace(M, N, K)) {
+        vitk_set_error("gemm_tn: workspace %zu < %zu", workspace_bytes, vitk_gemm_tn_workspace(M, N, K));
+        return VITK_ENOSPC;
+    }
+    const int splits = tn_splits(M, N, K);
+    GemmTNParams p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
+    p.slab = (float*)workspace;
+    p.colslab = dbias ? p.slab + (size_t)splits * N * K : nullptr;
+    p.M = M; p.N = N; p.K = K;
+    int mps = (M + splits - 1) / splits;
+    mps = ((mps + TBM - 1) / TBM) * TBM;
+    p.m_per_split = mps;
+    const int tiles_n = (N + GBN - 1) / GBN;
+    p.tiles_k = (K + GBN - 1) / GBN;
+    dim3 grid(tiles_n * p.tiles_k, splits);
+    hipStream_t s = (hipStream_t)stream;
+    const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K);
+    if (dbias) gemm_tn_kernel<true><<<grid, 256, 0, s>>>(p);
+    else gemm_tn_kernel<false><<<grid, 256, 0, s>>>(p);
+    if (pr) vitk_prof_end(stream);
+    int rc = vitk_check_launch("gemm_tn");
+    if (rc) return rc;
+    const size_t total4 = (size_t)N * K / 4;
+    int rgrid = (int)((total4 + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    reduce_slabs_kernel<<<rgrid, 256, 0, s>>>(p.slab, splits, N, K, C, ldc, accumulate);
+    rc = vitk_check_launch("gemm_tn_reduce");
+    if (rc) return rc;
+    if (dbias) {
+        reduce_vec_kernel<<<(N + 255) / 256, 256, 0, s>>>(p.colslab, splits, N, dbias, accumulate);
+        rc = vitk_check_launch("gemm_tn_reduce_bias");
+    }
+    return rc;
+}
+
+}  // extern "C"

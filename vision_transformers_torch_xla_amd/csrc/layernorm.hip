@@ -1,0 +1,228 @@
+// LayerNorm forward/backward for bf16 rows, one 64-lane wave per row, 16-byte loads, shuffle reductions.
+// HBM-bound: forward moves 4 B/element (read x, write y), backward 6 B/element (read dy, x; write dx)
+// plus 2 B/element when the residual gradient is fused in.
+#include "common.h"
+
+#define LN_ROWS_PER_BLOCK 4   // 4 waves of 64 lanes
+#define LN_MAX_BLOCKS 2048
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
+                                                      float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = D >> 3;
+    const float invD = 1.0f / (float)D;
+    for (int row = blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * LN_ROWS_PER_BLOCK) {
+        const bf16_t* xr = x + (size_t)row * D;
+        float v[NV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                load8(xr + 8 * c, v[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[i][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+            }
+        }
+        const float mu = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
+            }
+        }
+        const float var = wave_sum(q) * invD;
+        const float rs = 1.0f / sqrtf(var + eps);
+        bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                const float4 g0 = *reinterpret_cast<const float4*>(gamma + 8 * c);
+                const float4 g1 = *reinterpret_cast<const float4*>(gamma + 8 * c + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(beta + 8 * c);
+                const float4 b1 = *reinterpret_cast<const float4*>(beta + 8 * c + 4);
+                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+                store8(yr + 8 * c, o);
+            }
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+// Backward.  Each wave keeps per-lane column partials of dgamma/dbeta over all the rows it visits; the block
+// folds its 4 waves through LDS and writes one partial row; ln_bwd_reduce_kernel sums the partial rows in a
+// fixed order (deterministic).
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const bf16_t* __restrict__ dres,
+                                                      bf16_t* __restrict__ dx, float* __restrict__ partial /*[grid][2][D]*/,
+                                                      int M, int D) {
+    extern __shared__ __attribute__((aligned(16))) float ln_smem[];   // [4][2][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = D >> 3;
+    const float invD = 1.0f / (float)D;
+    float g[NV][8], dg[NV][8], db[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; g[i][j] = (c < nvec) ? gamma[8 * c + j] : 0.f; }
+    }
+    for (int row = blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * LN_ROWS_PER_BLOCK) {
+        const size_t off = (size_t)row * D;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[NV][8], gd[NV][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                float xv[8], dv[8];
+                load8(x + off + 8 * c, xv);
+                load8(dy + off + 8 * c, dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float h = (xv[j] - mu) * rs;
+                    xh[i][j] = h;
+                    dg[i][j] += dv[j] * h;
+                    db[i][j] += dv[j];
+                    const float t = dv[j] * g[i][j];
+                    gd[i][j] = t;
+                    s1 += t;
+                    s2 += t * h;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xh[i][j] = 0.f; gd[i][j] = 0.f; }
+            }
+        }
+        const float c1 = wave_sum(s1) * invD;
+        const float c2 = wave_sum(s2) * invD;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nvec) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = rs * (gd[i][j] - c1 - xh[i][j] * c2);
+                if (dres != nullptr) {
+                    float r[8];
+                    load8(dres + off + 8 * c, r);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += r[j];
+                }
+                store8(dx + off + 8 * c, o);
+            }
+        }
+    }
+    // fold the 4 waves
+    float* sg = ln_smem + (size_t)wave * 2 * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sg[8 * c + j] = dg[i][j]; sg[D + 8 * c + j] = db[i][j]; }
+        }
+    }
+    __syncthreads();
+    float* prow = partial + (size_t)blockIdx.x * 2 * D;
+    for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) {
+        prow[c] = ln_smem[c] + ln_smem[2 * D + c] + ln_smem[4 * D + c] + ln_smem[6 * D + c];
+    }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nrows, int D, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int accumulate) {
+    // block = 32 columns x 8 row groups; fixed summation order => bitwise reproducible
+    __shared__ float red[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    float s = 0.f;
+    if (c < 2 * D)
+        for (int r = ry; r < nrows; r += 8) s += partial[(size_t)r * 2 * D + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < 2 * D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cx];
+        float* dst = (c < D) ? (dgamma + c) : (dbeta + (c - D));
+        *dst = accumulate ? (*dst + t) : t;
+    }
+}
+
+static int ln_grid(int M) {
+    int g = (M + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+    return g < LN_MAX_BLOCKS ? g : LN_MAX_BLOCKS;
+}
+static int ln_bwd_grid(int M) {
+    int g = (M + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+    return g < 1024 ? g : 1024;
+}
+
+extern "C" {
+
+int vitk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
+                       int D, float eps, void* stream) {
+    VITK_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    VITK_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 1024, "layernorm_fwd: need M>0, D%%8==0, D<=1024 (M=%d D=%d)", M, D);
+    VITK_REQUIRE(vitk_aligned(x, 16) && vitk_aligned(y, 16) && vitk_aligned(gamma, 16) && vitk_aligned(beta, 16),
+                 "layernorm_fwd: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = ln_grid(M);
+    if (D <= 512)
+        ln_fwd_kernel<1><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+    else
+        ln_fwd_kernel<2><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+    return vitk_check_launch("layernorm_fwd");
+}
+
+size_t vitk_layernorm_bwd_workspace(int M, int D) {
+    if (M <= 0 || D <= 0) return 0;
+    return (size_t)ln_bwd_grid(M) * 2 * (size_t)D * sizeof(float);
+}
+
+int vitk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate, int M, int D,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    VITK_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
+    VITK_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 1024, "layernorm_bwd: need M>0, D%%8==0, D<=1024 (M=%d D=%d)", M, D);
+    VITK_REQUIRE(vitk_aligned(dy, 16) && vitk_aligned(x, 16) && vitk_aligned(dx, 16) && (!dres || vitk_aligned(dres, 16)),
+                 "layernorm_bwd: pointers must be 16-byte aligned");
+    if (workspace_bytes < vitk_layernorm_bwd_workspace(M, D)) {
+        vitk_set_error("layernorm_bwd: workspace %zu < %zu", workspace_bytes, vitk_layernorm_bwd_workspace(M, D));
+        return VITK_ENOSPC;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = ln_bwd_grid(M);
+    const size_t smem = (size_t)LN_ROWS_PER_BLOCK * 2 * D * sizeof(float);
+    float* partial = (float*)workspace;
+    if (D <= 512)
+        ln_bwd_kernel<1><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma,
+                                                  (const bf16_t*)dres, (bf16_t*)dx, partial, M, D);
+    else
+        ln_bwd_kernel<2><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma,
+                                                  (const bf16_t*)dres, (bf16_t*)dx, partial, M, D);
+    int rc = vitk_check_launch("layernorm_bwd");
+    if (rc) return rc;
+    ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 256, 0, s>>>(partial, grid, D, dgamma, dbeta, accumulate);
+    return vitk_check_launch("layernorm_bwd_reduce");
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+"""Tensor-level wrappers over the libvitk C ABI.
+
+PyTorch is used only as the owner of device memory and of the HIP stream: every function here checks
+device/dtype/contiguity, then hands raw device pointers, shapes and ``torch.cuda.current_stream()`` to one
+``vitk_*`` entry point.  Nothing falls back to a torch op; CPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_PATCH, EPI_PLAIN, check)
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.VitkError(f"{name}: expected a GPU tensor (the HIP kernels are the only implementation), got {t.device}")
+    if t.dtype != dtype:
+        raise _lib.VitkError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.VitkError(f"{name}: tensor must be contiguous")
+
+
+class Workspace:
+    """A growable device scratch buffer handed to kernels that need one (never allocated inside the library)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        nbytes = max(int(nbytes), 16)
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_default_ws = Workspace()
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, eps=1e-6):
+    """x bf16 [M,D] -> (y bf16 [M,D], mean fp32 [M], rstd fp32 [M])"""
+    _chk(x, bf16, "x"); _chk(gamma, f32, "gamma"); _chk(beta, f32, "beta")
+    M, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=f32, device=x.device)
+    rstd = torch.empty(M, dtype=f32, device=x.device)
+    check(_lib.load().vitk_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), M, D, eps, _stream()),
+          "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, accumulate=False, ws: Workspace = None, dx=None):
+    """Returns dx bf16 [M,D] (= LN backward of dy, plus dres when given); writes/accumulates dgamma, dbeta (fp32 [D])."""
+    _chk(dy, bf16, "dy"); _chk(x, bf16, "x"); _chk(gamma, f32, "gamma"); _chk(dgamma, f32, "dgamma"); _chk(dbeta, f32, "dbeta")
+    if dres is not None:
+        _chk(dres, bf16, "dres")
+    M, D = x.shape
+    lib = _lib.load()
+    need = lib.vitk_layernorm_bwd_workspace(M, D)
+    w = (ws or _default_ws).get(need, x.device)
+    if dx is None:
+        dx = torch.empty_like(x)
+    check(lib.vitk_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres), _ptr(dx), _ptr(dgamma),
+                                 _ptr(dbeta), int(accumulate), M, D, _ptr(w), w.numel(), _stream()), "layernorm_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------------- GEMM
+def gemm_nt(a, b, *, epilogue=EPI_PLAIN, bias=None, out=None, out_dtype=bf16, res=None, rowscale=None, rows_per_group=0,
+            out2=None, aux=None, pos=None, patches=0, prefix=0, out_rows=None):
+    """C[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue (see vitk.h).  a, b bf16; 2-D, last dim contiguous."""
+    for t, n in ((a, "a"), (b, "b")):
+        if not t.is_cuda or t.dtype != bf16 or t.dim() != 2 or t.stride(1) != 1:
+            raise _lib.VitkError(f"gemm_nt: {n} must be a 2-D bf16 GPU tensor with contiguous rows")
+    M, K = a.shape
+    N, Kb = b.shape
+    if K != Kb:
+        raise _lib.VitkError(f"gemm_nt: K mismatch {K} vs {Kb}")
+    if out is None:
+        rows = M if out_rows is None else out_rows
+        out = torch.empty((rows, N), dtype=(f32 if epilogue == EPI_BIAS_F32 else out_dtype), device=a.device)
+    if out.stride(-1) != 1:
+        raise _lib.VitkError("gemm_nt: out rows must be contiguous")
+    ldc = out.stride(0) if out.dim() == 2 else N
+    ldres = res.stride(0) if res is not None else 0
+    ldout2 = out2.stride(0) if out2 is not None else 0
+    ldaux = aux.stride(0) if aux is not None else 0
+    check(_lib.load().vitk_gemm_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), ldc, M, N, K, epilogue, _ptr(bias),
+                                   _ptr(res), ldres, _ptr(rowscale), rows_per_group, _ptr(out2), ldout2, _ptr(aux), ldaux,
+                                   _ptr(pos), patches, prefix, _stream()), "gemm_nt")
+    return out
+
+
+def gemm_tn(a, b, out, *, dbias=None, accumulate=False, ws: Workspace = None):
+    """out[N,K] (fp32) (+)= a[M,N]^T @ b[M,K]; optionally dbias[N] (+)= column sums of a."""
+    for t, n in ((a, "a"), (b, "b")):
+        if not t.is_cuda or t.dtype != bf16 or t.dim() != 2 or t.stride(1) != 1:
+            raise _lib.VitkError(f"gemm_tn: {n} must be a 2-D bf16 GPU tensor with contiguous rows")
+    M, N = a.shape
+    Mb, K = b.shape
+    if M != Mb:
+        raise _lib.VitkError(f"gemm_tn: M mismatch {M} vs {Mb}")
+    if out.dtype != f32 or tuple(out.shape) != (N, K) or out.stride(1) != 1:
+        raise _lib.VitkError(f"gemm_tn: out must be fp32 [{N},{K}] with contiguous rows")
+    lib = _lib.load()
+    need = lib.vitk_gemm_tn_workspace(M, N, K)
+    w = (ws or _default_ws).get(need, a.device)
+    check(lib.vitk_gemm_tn(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0), M, N, K, _ptr(dbias),
+                           int(accumulate), _ptr(w), w.numel(), _stream()), "gemm_tn")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention_fwd(qkv, B, N, H, scale):
+    """qkv bf16 [B*N, 3*H*64] -> (out bf16 [B*N, H*64], lse fp32 [B,H,N])"""
+    _chk(qkv, bf16, "qkv")
+    out = torch.empty((B * N, H * 64), dtype=bf16, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=f32, device=qkv.device)
+    check(_lib.load().vitk_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, N, H, scale, _stream()), "attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B, N, H, scale, ws: Workspace = None, dqkv=None):
+    _chk(qkv, bf16, "qkv"); _chk(out, bf16, "out"); _chk(dout, bf16, "dout"); _chk(lse, f32, "lse")
+    lib = _lib.load()
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    need = lib.vitk_attention_bwd_workspace(B, N, H)
+    w = (ws or _default_ws).get(need, qkv.device) if need else None
+    check(lib.vitk_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, N, H, scale, _ptr(w),
+                                 w.numel() if w is not None else 0, _stream()), "attention_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------- embedding / pooling
+def im2col_patches(img, p):
+    _chk(img, f32, "img")
+    B, Cc, Hh, Ww = img.shape
+    out = torch.empty((B * (Hh // p) * (Ww // p), Cc * p * p), dtype=bf16, device=img.device)
+    check(_lib.load().vitk_im2col_patches(_ptr(img), _ptr(out), B, Cc, Hh, Ww, p, _stream()), "im2col_patches")
+    return out
+
+
+def prefix_tokens_fwd(tokens, pos, x, B, N, D, prefix):
+    _chk(tokens, f32, "tokens"); _chk(pos, f32, "pos"); _chk(x, bf16, "x")
+    check(_lib.load().vitk_prefix_tokens_fwd(_ptr(tokens), _ptr(pos), _ptr(x), B, N, D, prefix, _stream()), "prefix_tokens_fwd")
+
+
+def pos_tokens_bwd(dx, dpos, dtokens, B, N, D, prefix, accumulate=False):
+    _chk(dx, bf16, "dx"); _chk(dpos, f32, "dpos")
+    check(_lib.load().vitk_pos_tokens_bwd(_ptr(dx), _ptr(dpos), _ptr(dtokens), int(accumulate), B, N, D, prefix, _stream()),
+          "pos_tokens_bwd")
+
+
+def pool_avg_fwd(x, B, N, D, first):
+    _chk(x, bf16, "x")
+    y = torch.empty((B, D), dtype=bf16, device=x.device)
+    check(_lib.load().vitk_pool_avg_fwd(_ptr(x), _ptr(y), B, N, D, first, _stream()), "pool_avg_fwd")
+    return y
+
+
+def pool_avg_bwd(dy, B, N, D, first, dx=None):
+    _chk(dy, bf16, "dy")
+    if dx is None:
+        dx = torch.empty((B * N, D), dtype=bf16, device=dy.device)
+    check(_lib.load().vitk_pool_avg_bwd(_ptr(dy), _ptr(dx), B, N, D, first, _stream()), "pool_avg_bwd")
+    return dx
+
+
+def gather_rows(x, B, N, D, token):
+    _chk(x, bf16, "x")
+    y = torch.empty((B, D), dtype=bf16, device=x.device)
+    check(_lib.load().vitk_gather_rows(_ptr(x), _ptr(y), B, N, D, token, _stream()), "gather_rows")
+    return y
+
+
+def scatter_rows(dy, dx, B, N, D, token, zero_others):
+    _chk(dy, bf16, "dy"); _chk(dx, bf16, "dx")
+    check(_lib.load().vitk_scatter_rows(_ptr(dy), _ptr(dx), B, N, D, token, int(zero_others), _stream()), "scatter_rows")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------- elementwise
+def rowscale(x, scale, rows_per_group, out=None):
+    _chk(x, bf16, "x"); _chk(scale, f32, "scale")
+    M, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().vitk_rowscale(_ptr(x), _ptr(scale), rows_per_group, _ptr(out), M, D, _stream()), "rowscale")
+    return out
+
+
+def cast_f32_to_bf16(src, dst=None):
+    _chk(src, f32, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=bf16, device=src.device)
+    check(_lib.load().vitk_cast_f32_to_bf16(_ptr(src), _ptr(dst), src.numel(), _stream()), "cast_f32_to_bf16")
+    return dst
+
+
+def cast_bf16_to_f32(src, dst=None):
+    _chk(src, bf16, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=f32, device=src.device)
+    check(_lib.load().vitk_cast_bf16_to_f32(_ptr(src), _ptr(dst), src.numel(), _stream()), "cast_bf16_to_f32")
+    return dst
+
+
+def transpose_bf16(src, dst=None):
+    _chk(src, bf16, "src")
+    rows, cols = src.shape
+    if dst is None:
+        dst = torch.empty((cols, rows), dtype=bf16, device=src.device)
+    check(_lib.load().vitk_transpose_bf16(_ptr(src), _ptr(dst), rows, cols, _stream()), "transpose_bf16")
+    return dst
+
+
+def add_bf16(a, b, out=None):
+    _chk(a, bf16, "a"); _chk(b, bf16, "b")
+    if out is None:
+        out = torch.empty_like(a)
+    check(_lib.load().vitk_add_bf16(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "add_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- losses
+def _logits2d(x, name):
+    if not x.is_cuda or x.dtype != f32 or x.dim() != 2 or x.stride(1) != 1:
+        raise _lib.VitkError(f"{name}: expected fp32 GPU logits [B,C] with contiguous rows")
+
+
+def xent_label(logits, target, smoothing, grad_scale, want_grad=True):
+    """-> (loss_rows fp32 [B], dlogits fp32 [B,C] or None)"""
+    _logits2d(logits, "xent_label")
+    _chk(target, torch.int64, "target")
+    Bn, Cn = logits.shape
+    loss_rows = torch.empty(Bn, dtype=f32, device=logits.device)
+    dl = torch.empty((Bn, Cn), dtype=f32, device=logits.device) if want_grad else None
+    check(_lib.load().vitk_xent_label_fwd_bwd(_ptr(logits), logits.stride(0), _ptr(target), float(smoothing), _ptr(loss_rows),
+                                              _ptr(dl), Cn, float(grad_scale), Bn, Cn, _stream()), "xent_label")
+    return loss_rows, dl
+
+
+def xent_soft(logits, target, grad_scale, want_grad=True):
+    _logits2d(logits, "xent_soft")
+    _logits2d(target, "xent_soft target")
+    Bn, Cn = logits.shape
+    loss_rows = torch.empty(Bn, dtype=f32, device=logits.device)
+    dl = torch.empty((Bn, Cn), dtype=f32, device=logits.device) if want_grad else None
+    check(_lib.load().vitk_xent_soft_fwd_bwd(_ptr(logits), logits.stride(0), _ptr(target), target.stride(0), _ptr(loss_rows),
+                                             _ptr(dl), Cn, float(grad_scale), Bn, Cn, _stream()), "xent_soft")
+    return loss_rows, dl
+
+
+def kd_kl(student, teacher, temperature, grad_scale, want_grad=True):
+    _logits2d(student, "kd_kl student")
+    _logits2d(teacher, "kd_kl teacher")
+    Bn, Cn = student.shape
+    loss_rows = torch.empty(Bn, dtype=f32, device=student.device)
+    ds = torch.empty((Bn, Cn), dtype=f32, device=student.device) if want_grad else None
+    check(_lib.load().vitk_kd_kl_fwd_bwd(_ptr(student), student.stride(0), _ptr(teacher), teacher.stride(0), float(temperature),
+                                         _ptr(loss_rows), _ptr(ds), Cn, float(grad_scale), Bn, Cn, _stream()), "kd_kl")
+    return loss_rows, ds
+
+
+def argmax_rows(logits):
+    _logits2d(logits, "argmax_rows")
+    Bn, Cn = logits.shape
+    idx = torch.empty(Bn, dtype=torch.int64, device=logits.device)
+    check(_lib.load().vitk_argmax_rows(_ptr(logits), logits.stride(0), _ptr(idx), Bn, Cn, _stream()), "argmax_rows")
+    return idx
+
+
+# ----------------------------------------------------------------------------------------------- optimizer
+def adamw_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, p_bf16=None, ema=None, ema_decay=0.0):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, f32, n)
+    check(_lib.load().vitk_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), _ptr(ema), float(ema_decay), p.numel(),
+                                      float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                      float(grad_scale), _stream()), "adamw_step")
+
+
+def sumsq(g, out, accumulate=False, ws: Workspace = None):
+    _chk(g, f32, "g"); _chk(out, f32, "out")
+    lib = _lib.load()
+    w = (ws or _default_ws).get(lib.vitk_sumsq_workspace(g.numel()), g.device)
+    check(lib.vitk_sumsq(_ptr(g), g.numel(), _ptr(out), int(accumulate), _ptr(w), w.numel(), _stream()), "sumsq")
+    return out
+
+
+def prof_enable(on: bool):
+    check(_lib.load().vitk_prof_enable(int(on)), "prof_enable")
+
+
+def prof_read():
+    import ctypes as C
+    ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+    check(_lib.load().vitk_prof_read(C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
+    return ms.value, fl.value, n.value
