@@ -102,6 +102,10 @@ int vitk_pool_avg_bwd(const void* dy, void* dx, int B, int N, int D, int first, 
 int vitk_gather_rows(const void* x, void* y, int B, int N, int D, int token, void* stream);
 int vitk_scatter_rows(const void* dy, void* dx, int B, int N, int D, int token, int zero_others, void* stream);
 
+/* y[b, t-first, :] = x[b, t, :] for t >= first: the patch-token rows without the prefix tokens (operand of the
+ * patch-embedding weight gradient; inverse of the torch.cat at models/vision_transformer.py:770-778) */
+int vitk_slice_tokens(const void* x, void* y, int B, int N, int D, int first, void* stream);
+
 /* ---- elementwise helpers */
 int vitk_rowscale(const void* x, const float* rowscale, int rows_per_group, void* y, int M, int D, void* stream);
 int vitk_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
@@ -131,6 +135,10 @@ int vitk_argmax_rows(const float* logits, int ld, int64_t* idx, int B, int C, vo
 int vitk_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, float* ema, float ema_decay,
                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     float grad_scale, void* stream);
+/* ema = decay*ema + (1-decay)*p over a flat fp32 range (timm ModelEma.update, engine.py:198-202,273-274) */
+int vitk_ema_update(float* ema, const float* p, float decay, int64_t n, void* stream);
+/* g *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) with sumsq[0] read on the device (torch clip_grad_norm_, engine.py:175-177) */
+int vitk_clip_grad_scale(float* g, int64_t n, const float* sumsq, float max_norm, void* stream);
 /* sum of squares of a flat fp32 range -> out[0] (+)=, for clip_grad_norm_ (engine.py:175-177) */
 int vitk_sumsq(const float* g, int64_t n, float* out, int accumulate, void* workspace, size_t workspace_bytes,
                void* stream);

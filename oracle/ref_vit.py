@@ -126,7 +126,41 @@ class RefViT(nn.Module):
             out.append(pair)
         return out
 
-    def forward(self, x, emulate=False, drop_scales=None):
+    def attn_half(self, blk, x, s1, E, tap=lambda k, v: None):
+        """x + drop_path1(attn(norm1(x)))   (models/vision_transformer.py:176); x [B,N,D]"""
+        w = lambda t: R.rnd(t, E, fwd=True, bwd=False)
+        act = lambda t: R.rnd(t, E, fwd=True, bwd=True)
+        y = act(R.layernorm(x, blk.norm1.weight, blk.norm1.bias))
+        tap('y1', y)
+        qkv = act(y @ w(blk.attn.qkv.weight).t() + blk.attn.qkv.bias)
+        tap('qkv', qkv)
+        o = R.rnd(R.attention(qkv, self.num_heads, emulate=E), E, fwd=False, bwd=True)
+        tap('o', o)
+        br = R.rnd(o @ w(blk.attn.proj.weight).t() + blk.attn.proj.bias, E, fwd=False, bwd=True)
+        if s1 is not None:
+            br = br * s1.to(br.dtype).reshape(-1, 1, 1)
+        out = act(x + br)
+        tap('x2', out)
+        return out
+
+    def mlp_half(self, blk, x, s2, E, tap=lambda k, v: None):
+        """x + drop_path2(mlp(norm2(x)))   (models/vision_transformer.py:177)"""
+        w = lambda t: R.rnd(t, E, fwd=True, bwd=False)
+        act = lambda t: R.rnd(t, E, fwd=True, bwd=True)
+        y = act(R.layernorm(x, blk.norm2.weight, blk.norm2.bias))
+        tap('y2', y)
+        f1 = act(y @ w(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias)
+        tap('h', f1)
+        a = R.rnd(R.gelu(f1), E, fwd=True, bwd=False)
+        tap('a', a)
+        br = R.rnd(a @ w(blk.mlp.fc2.weight).t() + blk.mlp.fc2.bias, E, fwd=False, bwd=True)
+        if s2 is not None:
+            br = br * s2.to(br.dtype).reshape(-1, 1, 1)
+        out = act(x + br)
+        tap('x3', out)
+        return out
+
+    def forward(self, x, emulate=False, drop_scales=None, taps=None):
         """x [B,C,H,W] fp32.  drop_scales: output of make_drop_scales (None: drawn here when training with drop path).
         emulate=True rounds to bf16 wherever the HIP kernels store bf16 (see ref_ops)."""
         E = emulate
@@ -150,22 +184,12 @@ class RefViT(nn.Module):
             pre.append(self.dist_token[0, 0] + pos[1])
         pre = torch.stack(pre, 0).unsqueeze(0).expand(B, -1, -1)
         h = act(torch.cat([pre, tok], dim=1))                   # [B,N,D]
+        tap = (lambda k, v: taps.__setitem__(k, v.detach())) if taps is not None else (lambda k, v: None)
+        tap('x0', h)
 
-        for blk, (s1, s2) in zip(self.blocks, drop_scales):
-            y = act(R.layernorm(h, blk.norm1.weight, blk.norm1.bias))
-            qkv = act(y @ w(blk.attn.qkv.weight).t() + blk.attn.qkv.bias)
-            o = R.rnd(R.attention(qkv, H, emulate=E), E, fwd=False, bwd=True)
-            br = gonly(o @ w(blk.attn.proj.weight).t() + blk.attn.proj.bias)
-            if s1 is not None:
-                br = br * s1.to(br.dtype).reshape(B, 1, 1)
-            h = act(h + br)
-            y = act(R.layernorm(h, blk.norm2.weight, blk.norm2.bias))
-            f1 = act(y @ w(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias)
-            a = R.rnd(R.gelu(f1), E, fwd=True, bwd=False)
-            br = gonly(a @ w(blk.mlp.fc2.weight).t() + blk.mlp.fc2.bias)
-            if s2 is not None:
-                br = br * s2.to(br.dtype).reshape(B, 1, 1)
-            h = act(h + br)
+        for li, (blk, (s1, s2)) in enumerate(zip(self.blocks, drop_scales)):
+            h = self.attn_half(blk, h, s1, E, lambda k, v: tap(f'{li}.{k}', v))
+            h = self.mlp_half(blk, h, s2, E, lambda k, v: tap(f'{li}.{k}', v))
 
         if self.global_pool == "avg":
             feat = act(h[:, npre:].mean(dim=1))                 # :431-433, prefix tokens excluded

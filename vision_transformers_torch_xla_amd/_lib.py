@@ -38,6 +38,7 @@ SIGNATURES = {
     "vitk_pool_avg_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vitk_gather_rows": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vitk_scatter_rows": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vitk_slice_tokens": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vitk_rowscale": (_i, [_p, _p, _i, _p, _i, _i, _p]),
     "vitk_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
     "vitk_cast_bf16_to_f32": (_i, [_p, _p, _i64, _p]),
@@ -48,6 +49,8 @@ SIGNATURES = {
     "vitk_kd_kl_fwd_bwd": (_i, [_p, _i, _p, _i, _f, _p, _p, _i, _f, _i, _i, _p]),
     "vitk_argmax_rows": (_i, [_p, _i, _p, _i, _i, _p]),
     "vitk_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _f, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
+    "vitk_ema_update": (_i, [_p, _p, _f, _i64, _p]),
+    "vitk_clip_grad_scale": (_i, [_p, _i64, _p, _f, _p]),
     "vitk_sumsq": (_i, [_p, _i64, _p, _i, _p, _sz, _p]),
     "vitk_sumsq_workspace": (_sz, [_i64]),
 }

@@ -128,6 +128,20 @@ __global__ void scatter_rows_kernel(const bf16_t* __restrict__ dy, bf16_t* __res
     }
 }
 
+// y[b][t-first][:] = x[b][t][:] for t >= first (drops the prefix tokens; compact patch-token rows)
+__global__ void slice_tokens_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int N, int D, int first) {
+    const int nv = D / 8;
+    const int T = N - first;
+    const size_t total = (size_t)B * T * nv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv) * 8;
+        const int t = (int)((i / nv) % T);
+        const int b = (int)(i / ((size_t)nv * T));
+        *reinterpret_cast<uint4*>(y + ((size_t)b * T + t) * D + c) =
+            *reinterpret_cast<const uint4*>(x + ((size_t)b * N + first + t) * D + c);
+    }
+}
+
 __global__ void rowscale_kernel(const bf16_t* __restrict__ x, const float* __restrict__ rowscale, int rows_per_group,
                                 bf16_t* __restrict__ y, int M, int D) {
     const int nv = D / 8;
@@ -247,6 +261,14 @@ int vitk_scatter_rows(const void* dy, void* dx, int B, int N, int D, int token, 
     const size_t total = zero_others ? (size_t)B * N * D / 8 : (size_t)B * D / 8;
     scatter_rows_kernel<<<ew_grid(total), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)dy, (bf16_t*)dx, B, N, D, token, zero_others);
     return vitk_check_launch("scatter_rows");
+}
+
+int vitk_slice_tokens(const void* x, void* y, int B, int N, int D, int first, void* stream) {
+    VITK_REQUIRE(x && y, "slice_tokens: null pointer");
+    VITK_REQUIRE(B > 0 && N > first && first >= 0 && D % 8 == 0, "slice_tokens: bad shape");
+    VITK_REQUIRE(vitk_aligned(x, 16) && vitk_aligned(y, 16), "slice_tokens: pointers must be 16-byte aligned");
+    slice_tokens_kernel<<<ew_grid((size_t)B * (N - first) * D / 8), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, B, N, D, first);
+    return vitk_check_launch("slice_tokens");
 }
 
 int vitk_rowscale(const void* x, const float* rowscale, int rows_per_group, void* y, int M, int D, void* stream) {

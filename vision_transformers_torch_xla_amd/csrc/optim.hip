@@ -84,7 +84,46 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
 
 #define SUMSQ_BLOCKS 1024
 
+// ema = decay * ema + (1 - decay) * p over a flat fp32 range
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, float decay, float omd, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 e = reinterpret_cast<float4*>(ema)[i];
+        const float4 q = reinterpret_cast<const float4*>(p)[i];
+        e.x = e.x * decay + omd * q.x; e.y = e.y * decay + omd * q.y;
+        e.z = e.z * decay + omd * q.z; e.w = e.w * decay + omd * q.w;
+        reinterpret_cast<float4*>(ema)[i] = e;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) ema[i] = ema[i] * decay + omd * p[i];
+}
+
+// g *= scale[0]-derived clip coefficient: coef = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))  (clip_grad_norm_)
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ sumsq, float max_norm) {
+    const float total = sqrtf(sumsq[0]);
+    float coef = max_norm / (total + 1e-6f);
+    if (coef >= 1.0f) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] *= coef;
+}
+
 extern "C" {
+
+int vitk_ema_update(float* ema, const float* p, float decay, int64_t n, void* stream) {
+    VITK_REQUIRE(ema && p && n > 0, "ema_update: bad arguments");
+    VITK_REQUIRE(vitk_aligned(ema, 16) && vitk_aligned(p, 16), "ema_update: pointers must be 16-byte aligned");
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    ema_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(ema, p, decay, (float)(1.0 - (double)decay), n);
+    return vitk_check_launch("ema_update");
+}
+
+int vitk_clip_grad_scale(float* g, int64_t n, const float* sumsq, float max_norm, void* stream) {
+    VITK_REQUIRE(g && sumsq && n > 0 && max_norm > 0.f, "clip_grad_scale: bad arguments");
+    clip_scale_kernel<<<2048, 256, 0, (hipStream_t)stream>>>(g, n, sumsq, max_norm);
+    return vitk_check_launch("clip_grad_scale");
+}
+
 
 int vitk_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, float* ema, float ema_decay, int64_t n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,

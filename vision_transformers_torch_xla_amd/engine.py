@@ -1,0 +1,164 @@
+"""train_one_epoch / evaluate with the reference's signatures (engine.py:19-24, :340), driving the HIP model.
+
+Kept from the reference (engine.py): the update_freq bookkeeping (:84-88), the per-iteration overwrite of every param
+group's lr (x lr_scale) and weight_decay from the schedules (:98-103), loss / update_freq before backward, optimizer
+step + zero_grad + EMA update every update_freq micro-steps (:268-274), optional grad-norm clipping (:175-177), train
+accuracy = argmax equality when mixup is off (:282-285), meters "loss", "lr", "class_acc" and the returned
+{name: global_avg} after a cross-rank sync (:290-299, :328-333); evaluate(): CrossEntropyLoss, top-1 / top-5,
+meters "loss", "acc1", "acc5" (:340-430).
+
+Changed on purpose (MI355X-first, same results): `tpu`, `use_amp` and `loss_scaler` are accepted and ignored (the model
+computes in bf16 with fp32 masters by construction; the reference's CUDA-AMP branch never trains, engine.py:109-118 vs
+:245-255); device scalars (loss, accuracy) are collected on the GPU and fetched in batches instead of one
+`.item()` host sync per step (engine.py:294-323); gradient averaging across ranks is the bucketed RCCL all-reduce
+overlapped with backward (dp.py) in place of xm.optimizer_step (:185).
+"""
+from __future__ import annotations
+
+import math
+import sys
+from typing import Iterable, Optional
+
+import torch
+
+from . import ops, utils
+from .losses import CrossEntropyLoss
+
+
+def _core_model(model):
+    m = model.module if hasattr(model, "module") else model
+    return m.student if hasattr(m, "student") else m
+
+
+def clip_grad_norm_(model, max_norm: float):
+    """torch.nn.utils.clip_grad_norm_ (L2) over the flat gradient buffer: one sum-of-squares reduction and one
+    scaling launch, the norm never leaves the GPU.  Returns the total norm as a 0-d GPU tensor."""
+    core = _core_model(model)
+    g = core._flat["g"]
+    if not hasattr(core, "_sumsq"):
+        core._sumsq = torch.zeros(1, dtype=torch.float32, device=g.device)
+    ops.sumsq(g, core._sumsq, ws=core._ws)
+    ops.clip_grad_scale(g, core._sumsq, max_norm)
+    return core._sumsq.sqrt()[0]
+
+
+class _DeferredMeters:
+    """Collects device scalars and resolves them with one host sync per flush instead of one per step."""
+
+    def __init__(self, logger, flush_every=64):
+        self.logger, self.flush_every, self.items = logger, flush_every, []
+
+    def add(self, name, tensor, n=1):
+        self.items.append((name, tensor.detach().reshape(()).float(), n))
+        if len(self.items) >= self.flush_every:
+            self.flush()
+
+    def flush(self):
+        if not self.items:
+            return
+        vals = torch.stack([t for _, t, _ in self.items]).tolist()
+        for (name, _, n), v in zip(self.items, vals):
+            self.logger.meters[name].update(v, n=n)
+        self.items = []
+
+
+def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loader: Iterable,
+                    optimizer: torch.optim.Optimizer, device: torch.device, epoch: int, loss_scaler=None, max_norm: float = 0,
+                    model_ema=None, mixup_fn=None, log_writer=None, wandb_logger=None, start_steps=None,
+                    lr_schedule_values=None, wd_schedule_values=None, num_training_steps_per_epoch=None, update_freq=None,
+                    use_amp=False, tpu: bool = False, log_freq: int = 10):
+    model.train(True)
+    update_freq = update_freq or 1
+    start_steps = start_steps or 0
+    if log_writer is not None and num_training_steps_per_epoch is not None:
+        log_writer.set_step(epoch * num_training_steps_per_epoch * update_freq)
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    deferred = _DeferredMeters(metric_logger)
+    header = f"Epoch: [{epoch}]"
+    reducer = getattr(model, "reducer", None)
+    optimizer.zero_grad()
+
+    for data_iter_step, (samples, targets) in enumerate(data_loader):
+        step = data_iter_step // update_freq
+        if num_training_steps_per_epoch is not None and step >= num_training_steps_per_epoch:
+            continue
+        it = start_steps + step
+        if (lr_schedule_values is not None or wd_schedule_values is not None) and data_iter_step % update_freq == 0:
+            for param_group in optimizer.param_groups:
+                if lr_schedule_values is not None:
+                    param_group["lr"] = lr_schedule_values[it] * param_group.get("lr_scale", 1.0)
+                if wd_schedule_values is not None and param_group.get("weight_decay", None) is not None:
+                    param_group["weight_decay"] = wd_schedule_values[it]
+
+        if mixup_fn is not None:
+            samples, targets = mixup_fn(samples, targets)
+        samples = samples.to(device, non_blocking=True)
+        targets = targets.to(device, non_blocking=True)
+
+        last_micro = (data_iter_step + 1) % update_freq == 0
+        if reducer is not None:
+            reducer.enabled = last_micro          # gradient accumulation: only the last micro-step communicates
+        output = model(samples)
+        loss = criterion(output, targets)
+        if update_freq > 1:
+            loss = loss / update_freq
+        loss.backward()
+        if last_micro:
+            if reducer is not None:
+                reducer.wait()
+            if max_norm is not None and max_norm > 0:
+                clip_grad_norm_(model, max_norm)
+            optimizer.step()
+            optimizer.zero_grad()
+            if model_ema is not None:
+                model_ema.update(model)
+
+        class_acc = None
+        if mixup_fn is None:
+            out0 = output[0] if isinstance(output, tuple) else output
+            class_acc = (ops.argmax_rows(out0.detach().float()) == targets).float().mean()
+
+        if data_iter_step % log_freq == 0 or data_iter_step < 5:
+            deferred.add("loss", loss)
+            if class_acc is not None:
+                deferred.add("class_acc", class_acc, n=samples.size(0))
+            metric_logger.update(lr=optimizer.param_groups[0]["lr"])
+        if log_writer is not None or wandb_logger is not None:
+            deferred.flush()
+            lv = metric_logger.meters["loss"].value if metric_logger.meters["loss"].count else float("nan")
+            if log_writer is not None:
+                log_writer.update(loss=lv, lr=optimizer.param_groups[0]["lr"])
+
+    deferred.flush()
+    if "loss" in metric_logger.meters and not math.isfinite(metric_logger.meters["loss"].global_avg):
+        print("Loss is {}, stopping training".format(metric_logger.meters["loss"].global_avg))
+        sys.exit(1)
+    metric_logger.synchronize_between_processes()
+    if utils.is_main_process():
+        print(header, "Averaged stats:", metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+@torch.no_grad()
+def evaluate(data_loader, model, device, use_amp=False, tpu: bool = False):
+    criterion = CrossEntropyLoss()
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    deferred = _DeferredMeters(metric_logger)
+    model.eval()
+    for batch in data_loader:
+        images, target = batch[0], batch[-1]
+        images = images.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        output = model(images)
+        loss = criterion(output, target)
+        acc1, acc5 = utils.accuracy(output, target, topk=(1, 5))
+        bs = images.shape[0]
+        deferred.add("loss", loss)
+        deferred.add("acc1", acc1, n=bs)
+        deferred.add("acc5", acc5, n=bs)
+    deferred.flush()
+    metric_logger.synchronize_between_processes()
+    if utils.is_main_process() and metric_logger.meters:
+        print("* Acc@1 {top1.global_avg:.3f} Acc@5 {top5.global_avg:.3f} loss {losses.global_avg:.3f}".format(
+            top1=metric_logger.meters["acc1"], top5=metric_logger.meters["acc5"], losses=metric_logger.meters["loss"]))
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}

@@ -192,6 +192,13 @@ def scatter_rows(dy, dx, B, N, D, token, zero_others):
     return dx
 
 
+def slice_tokens(x, B, N, D, first):
+    _chk(x, bf16, "x")
+    y = torch.empty((B * (N - first), D), dtype=bf16, device=x.device)
+    check(_lib.load().vitk_slice_tokens(_ptr(x), _ptr(y), B, N, D, first, _stream()), "slice_tokens")
+    return y
+
+
 # ------------------------------------------------------------------------------------------- elementwise
 def rowscale(x, scale, rows_per_group, out=None):
     _chk(x, bf16, "x"); _chk(scale, f32, "scale")
@@ -298,6 +305,16 @@ def sumsq(g, out, accumulate=False, ws: Workspace = None):
     w = (ws or _default_ws).get(lib.vitk_sumsq_workspace(g.numel()), g.device)
     check(lib.vitk_sumsq(_ptr(g), g.numel(), _ptr(out), int(accumulate), _ptr(w), w.numel(), _stream()), "sumsq")
     return out
+
+
+def ema_update(ema, p, decay):
+    _chk(ema, f32, "ema"); _chk(p, f32, "p")
+    check(_lib.load().vitk_ema_update(_ptr(ema), _ptr(p), float(decay), p.numel(), _stream()), "ema_update")
+
+
+def clip_grad_scale(g, sumsq_t, max_norm):
+    _chk(g, f32, "g"); _chk(sumsq_t, f32, "sumsq")
+    check(_lib.load().vitk_clip_grad_scale(_ptr(g), g.numel(), _ptr(sumsq_t), float(max_norm), _stream()), "clip_grad_scale")
 
 
 def prof_enable(on: bool):

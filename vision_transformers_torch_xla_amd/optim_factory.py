@@ -1,0 +1,206 @@
+"""Optimizer construction for the ViT training step, with AdamW fused into one HIP launch per parameter group.
+
+Mirrors optim_factory.py of the reference: get_parameter_groups (:70-211, non-TPU branch :151-195: a parameter goes to the
+"no_decay" group when it is 1-D, a ".bias", or named by model.no_weight_decay(); groups carry "lr_scale"),
+create_optimizer(args, model, get_num_layer, get_layer_scale, filter_bias_and_bn, skip_list) (:214-296) and
+LayerDecayValueAssigner (:59-67).  Only the optimizer the reference's scripts select, AdamW (:248-249, main.py:171),
+is implemented; other --opt names raise.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import VitkError
+
+
+class LayerDecayValueAssigner(object):
+    def __init__(self, values, get_layer_id=None):
+        self.values = values
+        self._get_layer_id = get_layer_id
+
+    def get_scale(self, layer_id):
+        return self.values[layer_id]
+
+    def get_layer_id(self, var_name):
+        if self._get_layer_id is None:
+            raise VitkError("LayerDecayValueAssigner: pass get_layer_id= (the reference only ships a ConvNeXt layer map)")
+        return self._get_layer_id(var_name)
+
+
+def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None):
+    parameter_group_names = {}
+    parameter_group_vars = {}
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if len(param.shape) == 1 or name.endswith(".bias") or name in skip_list:
+            group_name, this_weight_decay = "no_decay", 0.0
+        else:
+            group_name, this_weight_decay = "decay", weight_decay
+        layer_id = None
+        if get_num_layer is not None:
+            layer_id = get_num_layer(name)
+            group_name = "layer_%d_%s" % (layer_id, group_name)
+        if group_name not in parameter_group_names:
+            scale = get_layer_scale(layer_id) if get_layer_scale is not None else 1.0
+            parameter_group_names[group_name] = {"weight_decay": this_weight_decay, "params": [], "lr_scale": scale}
+            parameter_group_vars[group_name] = {"weight_decay": this_weight_decay, "params": [], "lr_scale": scale}
+        parameter_group_vars[group_name]["params"].append(param)
+        parameter_group_names[group_name]["params"].append(name)
+    return list(parameter_group_vars.values())
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction, eps outside the sqrt) executed by
+    vitk_adamw_step over contiguous ranges of the model's flat parameter buffer: reads p, g, m, v and writes p, m, v
+    plus the bf16 weight copy in one pass.  `param_groups` behave as usual (the training loop overwrites "lr" and
+    "weight_decay" every iteration, engine.py:98-103).  Parameters that do not belong to a flat-buffer model are
+    updated by one launch each."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None):
+        if lr < 0.0 or eps < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("FusedAdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._model = model
+        self._steps = 0
+        self.grad_scale = 1.0          # extra factor on the gradients (e.g. 1/world_size after a SUM all-reduce)
+        self._plan = None
+        self._m = self._v = None
+
+    # -- planning: map every param group onto contiguous ranges of the flat buffer
+    def _build_plan(self):
+        model = self._model
+        plan = []
+        if model is not None and hasattr(model, "_flat") and not model._views_ok():
+            model._flatten()
+        flat_ok = model is not None and hasattr(model, "_flat")
+        if flat_ok:
+            flat_p = model._flat["p"]
+            base = flat_p.data_ptr()
+            self._m = torch.zeros_like(flat_p)
+            self._v = torch.zeros_like(flat_p)
+            name_of = {id(p): n for n, p in zip(model._pnames, model._plist)}
+            order = {n: i for i, n in enumerate(model._pnames)}
+        for gi, group in enumerate(self.param_groups):
+            ranges, loose = [], []
+            if flat_ok:
+                inside = sorted((p for p in group["params"] if id(p) in name_of), key=lambda p: order[name_of[id(p)]])
+                loose = [p for p in group["params"] if id(p) not in name_of]
+                cur = None
+                for p in inside:
+                    i = order[name_of[id(p)]]
+                    start = (p.data_ptr() - base) // 4
+                    # the range may run up to the next parameter's offset (alignment padding holds zeros)
+                    nxt = model._offs[model._pnames[i + 1]] if i + 1 < len(model._pnames) else model._total
+                    if cur is not None and cur[2] == i - 1 and cur[1] == start:
+                        cur[1], cur[2] = nxt, i
+                    else:
+                        cur = [start, nxt, i]
+                        ranges.append(cur)
+                    self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self._m[start:start + p.numel()].view(p.shape),
+                                     "exp_avg_sq": self._v[start:start + p.numel()].view(p.shape)}
+            else:
+                loose = list(group["params"])
+            for p in loose:
+                if p not in self.state or "exp_avg" not in self.state[p]:
+                    self.state[p] = {"step": torch.tensor(0.0), "exp_avg": torch.zeros_like(p, dtype=torch.float32),
+                                     "exp_avg_sq": torch.zeros_like(p, dtype=torch.float32)}
+            plan.append(([(r[0], r[1]) for r in ranges], loose))
+        self._plan = plan
+        self._plan_key = (model._flat["p"].data_ptr() if flat_ok else None, tuple(len(g["params"]) for g in self.param_groups))
+
+    def _plan_stale(self):
+        if self._plan is None:
+            return True
+        model = self._model
+        key = (model._flat["p"].data_ptr() if (model is not None and hasattr(model, "_flat")) else None,
+               tuple(len(g["params"]) for g in self.param_groups))
+        return key != self._plan_key
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._plan_stale():
+            self._build_plan()
+        self._steps += 1
+        model = self._model
+        for group, (ranges, loose) in zip(self.param_groups, self._plan):
+            b1, b2 = group["betas"]
+            kw = dict(lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"], step=self._steps,
+                      grad_scale=self.grad_scale)
+            for (a, b) in ranges:
+                f = model._flat
+                ops.adamw_step(f["p"][a:b], f["g"][a:b], self._m[a:b], self._v[a:b], p_bf16=f["b"][a:b], **kw)
+            for p in loose:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise VitkError("FusedAdamW: parameters must be on the GPU")
+                st = self.state[p]
+                ops.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), **kw)
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = torch.tensor(float(self._steps))
+        if model is not None and hasattr(model, "_refresh_transposes"):
+            model._refresh_transposes()                      # bf16 copies were written by the kernel itself
+            model._weights_version = model._version_key()
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        """For the flat-buffer model this only marks the gradient buffer stale (the next backward overwrites it)."""
+        model = self._model
+        if model is not None and hasattr(model, "_flat"):
+            model.zero_grad(set_to_none=False)
+            own = {id(p) for p in model._plist}
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if id(p) not in own and p.grad is not None:
+                        p.grad = None if set_to_none else p.grad.zero_()
+            return
+        super().zero_grad(set_to_none=set_to_none)
+
+    def load_state_dict(self, state_dict):
+        """Restores torch-AdamW-format state into the flat moment buffers."""
+        steps = [float(s["step"]) for s in state_dict.get("state", {}).values() if "step" in s]
+        if self._plan_stale():
+            self._build_plan()
+        views = {id(p): (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items() if "exp_avg" in st}
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            for p, st in self.state.items():
+                if id(p) in views and "exp_avg" in st:
+                    m, v = views[id(p)]
+                    m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                    st["exp_avg"], st["exp_avg_sq"] = m, v
+        if steps:
+            self._steps = int(max(steps))
+
+
+def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):
+    opt_lower = args.opt.lower()
+    weight_decay = args.weight_decay
+    if filter_bias_and_bn:
+        skip = {}
+        if skip_list is not None:
+            skip = skip_list
+        elif hasattr(model, "no_weight_decay"):
+            skip = model.no_weight_decay()
+        parameters = get_parameter_groups(model, weight_decay, skip, get_num_layer, get_layer_scale)
+        weight_decay = 0.0
+    else:
+        parameters = model.parameters()
+    opt_args = dict(lr=args.lr, weight_decay=weight_decay)
+    if getattr(args, "opt_eps", None) is not None:
+        opt_args["eps"] = args.opt_eps
+    if getattr(args, "opt_betas", None) is not None:
+        opt_args["betas"] = tuple(args.opt_betas)
+    opt_split = opt_lower.split("_")
+    opt_lower = opt_split[-1]
+    if opt_lower in ("adamw", "fusedadamw"):
+        flat_model = model if hasattr(model, "_flat") else None
+        return FusedAdamW(parameters, model=flat_model, **opt_args)
+    raise VitkError(f"optimizer {args.opt!r} is not implemented: the ViT recipes of the reference use adamw (main.py:171)")

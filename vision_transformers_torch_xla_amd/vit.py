@@ -1,0 +1,548 @@
+"""Vision Transformer whose forward AND backward run as hand-written gfx950 HIP kernels (libvitk), behind the
+reference's timm-style surface.
+
+Mirrors (reference file:line, under /root/reference):
+  models/vision_transformer.py:444-623  VisionTransformer constructor rules (use_fc_norm :529, dpr linspace :581,
+                                        norm / fc_norm placement :603,616), :634-648 + :998-1010 weight init,
+                                        :666-668 no_weight_decay(), :743-780 _pos_embed, :934-995 forward, :419-441 pool
+  models/vision_transformer.py:109-178  Block: x += dp(attn(ln1 x)); x += dp(mlp(ln2 x))
+  models/deit.py:28-119                 distilled variant (dist_token, head_dist, two prefix tokens)
+  models/_factory.py:46-155             create_model(name, pretrained=False, **kwargs), unknown name -> RuntimeError
+  models/vision_transformer.py:2690-2860, models/my_vit.py:84-165   model size table
+State-dict keys are timm's (cls_token, pos_embed, patch_embed.proj.*, blocks.N.norm1.*, blocks.N.attn.qkv.*, ...), so
+checkpoints move between the reference and this model unchanged.
+
+Design: all parameters live in ONE flat fp32 buffer (master weights) with a same-layout flat fp32 gradient buffer
+and a flat bf16 copy that the MFMA GEMMs read; nn.Parameters are views.  The layout is
+[decay weights: head, blocks L-1..0, patch | no-decay: tokens, pos, biases, norms] so that (a) fused AdamW is two
+launches, (b) gradients become final in increasing address order during backward, which is what the data-parallel
+reducer buckets on.  One torch.autograd.Function spans the whole network; its backward writes straight into the flat
+gradient buffer (param.grad are views of it).
+There is no CPU path: tensors must live on the GPU and libvitk.so must be built.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import (EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_PATCH, EPI_PLAIN, VitkError)
+
+bf16, f32 = torch.bfloat16, torch.float32
+_ALIGN = 64   # flat-buffer offsets are multiples of 64 elements (256 B fp32 / 128 B bf16)
+
+
+class _Linear(nn.Module):
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        self.in_features, self.out_features = in_f, out_f
+        self.weight = nn.Parameter(torch.empty(out_f, in_f))
+        self.bias = nn.Parameter(torch.zeros(out_f))
+
+
+class _LayerNorm(nn.Module):
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = _Linear(dim, 3 * dim)
+        self.proj = _Linear(dim, dim)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = _Linear(dim, hidden)
+        self.fc2 = _Linear(hidden, dim)
+
+
+class Block(nn.Module):
+    """Parameter holder of one pre-norm block (models/vision_transformer.py:109-178); the math runs in libvitk."""
+
+    def __init__(self, dim, heads, mlp_ratio, drop_path):
+        super().__init__()
+        self.norm1 = _LayerNorm(dim)
+        self.attn = _Attention(dim, heads)
+        self.norm2 = _LayerNorm(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.drop_path = float(drop_path)
+
+
+class _PatchProj(nn.Module):
+    def __init__(self, in_chans, dim, patch):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(dim, in_chans, patch, patch))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch, in_chans, dim):
+        super().__init__()
+        self.img_size, self.patch_size = (img_size, img_size), (patch, patch)
+        self.grid_size = (img_size // patch, img_size // patch)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = _PatchProj(in_chans, dim, patch)
+
+
+class _ViTFunction(torch.autograd.Function):
+    """forward = all layers through libvitk, keeping what backward needs; backward fills the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, img, model, scales, *params):
+        outs, saved = model._forward_impl(img, scales, save=True)
+        ctx.model, ctx.saved, ctx.nout = model, saved, len(outs)
+        return outs[0] if len(outs) == 1 else tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        model, saved = ctx.model, ctx.saved
+        ctx.saved = None
+        model._backward_impl(saved, list(douts))
+        return (None, None, None) + (None,) * len(model._plist)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, global_pool="token", embed_dim=768,
+                 depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.0, distilled=False,
+                 weight_init="", **kwargs):
+        super().__init__()
+        unsupported = {k: v for k, v in kwargs.items() if v not in (None, False, 0, 0.0, "")}
+        for k in ("class_token", "final_norm", "pretrained_cfg", "pretrained_cfg_overlay", "cache_dir"):
+            unsupported.pop(k, None)
+        if unsupported:
+            raise VitkError(f"VisionTransformer: options outside the ViT training hot path are not implemented: {sorted(unsupported)}")
+        if global_pool not in ("avg", "token"):
+            raise VitkError(f"global_pool={global_pool!r} not implemented (have 'avg', 'token')")
+        if distilled and global_pool != "token":
+            raise VitkError("distilled models require global_pool='token' (models/deit.py:38)")
+        if not qkv_bias:
+            raise VitkError("qkv_bias=False not implemented")
+        if embed_dim % num_heads or embed_dim // num_heads != 64:
+            raise VitkError(f"the fused attention kernel supports head dim 64 only (embed_dim={embed_dim}, heads={num_heads})")
+        if patch_size % 8 or img_size % patch_size:
+            raise VitkError("patch_size must be a multiple of 8 and divide img_size")
+        if num_classes % 8:
+            raise VitkError("num_classes must be a multiple of 8 (MFMA GEMM alignment)")
+        if embed_dim > 1024 or embed_dim % 8:
+            raise VitkError("embed_dim must be a multiple of 8 and <= 1024 (LayerNorm kernel)")
+        self.num_classes, self.global_pool, self.distilled = num_classes, global_pool, distilled
+        self.num_features = self.head_hidden_size = self.embed_dim = embed_dim
+        self.depth, self.num_heads, self.patch_size, self.in_chans = depth, num_heads, patch_size, in_chans
+        self.num_prefix_tokens = 2 if distilled else 1
+        self.has_class_token = True
+        self.drop_path_rate = drop_path_rate
+        self.distilled_training = False
+        use_fc_norm = global_pool == "avg"                                   # vision_transformer.py:529
+
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.num_patches = self.patch_embed.num_patches
+        self.num_tokens = self.num_patches + self.num_prefix_tokens
+        if self.num_tokens > 608:
+            raise VitkError(f"{self.num_tokens} tokens exceed the fused attention kernel's limit (608)")
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        if distilled:
+            self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_tokens, embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]  # vision_transformer.py:581
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, dpr[i]) for i in range(depth)])
+        if use_fc_norm:
+            self.fc_norm = _LayerNorm(embed_dim)                             # :616
+        else:
+            self.norm = _LayerNorm(embed_dim)                                # :603
+        self.head = _Linear(embed_dim, num_classes)
+        if distilled:
+            self.head_dist = _Linear(embed_dim, num_classes)
+        self._forced_drop_scales = None      # tests inject per-layer DropPath factors here
+        self._bwd_taps = None                # tests: dict that receives per-layer intermediate gradients
+        self._grad_ready_hook = None         # data-parallel reducer: called with the flat offset below which grads are final
+        self._ws = ops.Workspace()
+        self._flat = None
+        if weight_init != "skip":
+            self.init_weights()
+        self._flatten()
+
+    # ------------------------------------------------------------------------------------------- parameters
+    def init_weights(self, mode: str = ""):
+        """timm-mode init: trunc-normal(.02) for pos_embed and every Linear weight, zero biases, cls ~ N(0, 1e-6)
+        (vision_transformer.py:634-648, 998-1010; deit.py:49-51).  The patch Conv2d keeps torch's default init."""
+        with torch.no_grad():
+            nn.init.trunc_normal_(self.pos_embed, std=0.02, a=-2.0, b=2.0)
+            nn.init.normal_(self.cls_token, std=1e-6)
+            if self.distilled:
+                nn.init.trunc_normal_(self.dist_token, std=0.02, a=-2.0, b=2.0)
+            for m in self.modules():
+                if isinstance(m, _Linear):
+                    nn.init.trunc_normal_(m.weight, std=0.02, a=-2.0, b=2.0)
+                    nn.init.zeros_(m.bias)
+            w = self.patch_embed.proj.weight
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))                      # nn.Conv2d.reset_parameters
+            bound = 1.0 / math.sqrt(w[0].numel())
+            nn.init.uniform_(self.patch_embed.proj.bias, -bound, bound)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token", "dist_token"}                      # vision_transformer.py:668
+
+    def set_distilled_training(self, enable=True):
+        self.distilled_training = enable                                     # deit.py:72-73
+
+    def get_classifier(self):
+        return (self.head, self.head_dist) if self.distilled else self.head
+
+    def _flat_order(self):
+        """[(name, param)] in flat-buffer order and the number of leading 'decay' entries.  Decay = what
+        optim_factory.get_parameter_groups puts in its weight-decay group (optim_factory.py:164)."""
+        named = dict(self.named_parameters())
+        skip = self.no_weight_decay()
+        is_nd = lambda n, p: p.dim() == 1 or n.endswith(".bias") or n in skip
+        decay = ["head.weight"] + (["head_dist.weight"] if self.distilled else [])
+        for i in reversed(range(self.depth)):
+            decay += [f"blocks.{i}.mlp.fc2.weight", f"blocks.{i}.mlp.fc1.weight", f"blocks.{i}.attn.proj.weight", f"blocks.{i}.attn.qkv.weight"]
+        decay += ["patch_embed.proj.weight"]
+        assert all(not is_nd(n, named[n]) for n in decay)
+        first_nd = ["cls_token"] + (["dist_token"] if self.distilled else []) + ["pos_embed"]
+        rest = [n for n, p in named.items() if n not in decay and n not in first_nd]
+        assert all(is_nd(n, named[n]) for n in first_nd + rest), "unexpected weight-decay parameter outside the layout"
+        order = decay + first_nd + rest
+        return [(n, named[n]) for n in order], len(decay)
+
+    def _flatten(self, device=None):
+        """(Re)build the flat master / gradient / bf16 buffers on `device` and re-point every Parameter into them."""
+        order, ndecay = self._flat_order()
+        device = torch.device(device) if device is not None else order[0][1].device
+        offs, off = {}, 0
+        for k, (n, p) in enumerate(order):
+            if k == ndecay:
+                decay_end = off
+            offs[n] = off
+            nel = p.numel()
+            # cls/dist tokens must be adjacent (they are read as one [prefix, D] table): D is a multiple of 8 and
+            # D*4 bytes keeps 16-byte alignment, so no padding between them
+            pad = nel if n in ("cls_token",) and self.distilled else ((nel + _ALIGN - 1) // _ALIGN) * _ALIGN
+            off += pad
+        total = off
+        flat_p = torch.zeros(total, dtype=f32, device=device)
+        flat_g = torch.zeros(total, dtype=f32, device=device)
+        with torch.no_grad():
+            for n, p in order:
+                flat_p[offs[n]:offs[n] + p.numel()].copy_(p.detach().reshape(-1).to(device=device, dtype=f32))
+        self._offs, self._total, self._decay_end = offs, total, decay_end
+        self._flat = {"p": flat_p, "g": flat_g, "b": torch.zeros(total, dtype=bf16, device=device)}
+        self._plist, self._gview = [], {}
+        for n, p in order:
+            sl = slice(offs[n], offs[n] + p.numel())
+            p.data = flat_p[sl].view(p.shape)
+            self._gview[n] = flat_g[sl].view(p.shape)
+            p.grad = None
+            self._plist.append(p)
+        self._pnames = [n for n, _ in order]
+        self._grad_valid = False
+        self._wt = {}
+        self._weights_version = None
+        # bucket boundaries for gradient reduction: grads below boundary k are final once stage k of backward is done
+        self._layer_end = {}
+        for i in range(self.depth):
+            n = f"blocks.{i}.attn.qkv.weight"
+            self._layer_end[i] = offs[n] + dict(order)[n].numel()
+        n = "head_dist.weight" if self.distilled else "head.weight"
+        self._head_end = offs[n] + dict(order)[n].numel()
+        self._build_views()
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn)
+        if self._flat is not None:
+            self._flatten()
+        return self
+
+    def zero_grad(self, set_to_none: bool = True):
+        """Marks the flat gradient buffer stale: the next backward overwrites it instead of accumulating (no memset)."""
+        self._grad_valid = False
+        if set_to_none:
+            for p in self._plist:
+                p.grad = None
+
+    def _version_key(self):
+        return sum(p._version for p in self._plist)
+
+    def _sync_weights(self, force=False):
+        """bf16 copy of every weight + transposed copies for the data-gradient GEMMs, refreshed when the fp32 masters
+        changed through torch (load_state_dict, a foreign optimizer).  FusedAdamW refreshes them itself."""
+        if not self._views_ok():            # e.g. after copy.deepcopy(model): parameters no longer alias the flat buffer
+            self._flatten()
+        key = self._version_key()
+        if not force and self._weights_version == key:
+            return
+        if not self._flat["p"].is_cuda:
+            raise VitkError("the model must be on the GPU (model.cuda()): libvitk is the only implementation")
+        ops.cast_f32_to_bf16(self._flat["p"], self._flat["b"])
+        self._refresh_transposes()
+        self._weights_version = key
+
+    def _build_views(self):
+        """2-D views into the flat buffers: bf16 GEMM weights [out, in], the prefix-token table, the position table."""
+        self._wb = {}
+        for n, p in zip(self._pnames, self._plist):
+            if p.dim() >= 2 and n not in ("cls_token", "dist_token", "pos_embed"):
+                off, rows = self._offs[n], p.shape[0]
+                self._wb[n] = self._flat["b"][off:off + p.numel()].view(rows, p.numel() // rows)
+        D, npre = self.embed_dim, self.num_prefix_tokens
+        o = self._offs["cls_token"]
+        self._tokens = self._flat["p"][o:o + npre * D].view(npre, D)
+        self._gtokens = self._flat["g"][o:o + npre * D].view(npre, D)
+        o = self._offs["pos_embed"]
+        self._pos2d = self._flat["p"][o:o + self.num_tokens * D].view(self.num_tokens, D)
+        self._gpos2d = self._flat["g"][o:o + self.num_tokens * D].view(self.num_tokens, D)
+
+    def _refresh_transposes(self):
+        """[in, out] bf16 copies of the linears: the data-gradient GEMM dX = dY @ W runs as gemm_nt(dY, W^T)."""
+        for n, src in self._wb.items():
+            if n == "patch_embed.proj.weight":      # the image needs no gradient
+                continue
+            dst = self._wt.get(n)
+            if dst is None or dst.device != src.device:
+                dst = torch.empty((src.shape[1], src.shape[0]), dtype=bf16, device=src.device)
+                self._wt[n] = dst
+            ops.transpose_bf16(src, dst)
+
+    def _views_ok(self):
+        p0, off0 = self._plist[0], self._offs[self._pnames[0]]
+        p1, off1 = self._plist[-1], self._offs[self._pnames[-1]]
+        base = self._flat["p"].data_ptr()
+        return p0.data_ptr() == base + 4 * off0 and p1.data_ptr() == base + 4 * off1
+
+    # ---------------------------------------------------------------------------------------------- forward
+    def _draw_drop_scales(self, B, device):
+        """DropPath (timm drop_path, scale_by_keep): per sample Bernoulli(keep)/keep, one draw per residual branch."""
+        if self._forced_drop_scales is not None:
+            return [tuple(None if s is None else s.to(device=device, dtype=f32).contiguous() for s in pair)
+                    for pair in self._forced_drop_scales]
+        out = []
+        for blk in self.blocks:
+            if self.training and blk.drop_path > 0.0:
+                keep = 1.0 - blk.drop_path
+                out.append(tuple(torch.empty(B, dtype=f32, device=device).bernoulli_(keep).div_(keep) for _ in range(2)))
+            else:
+                out.append((None, None))
+        return out
+
+    def forward(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise VitkError("VisionTransformer.forward: input must be a GPU tensor; this model has no CPU implementation")
+        if x.dim() != 4 or x.shape[1] != self.in_chans or x.shape[2] != self.patch_embed.img_size[0] or x.shape[3] != self.patch_embed.img_size[1]:
+            raise VitkError(f"input shape {tuple(x.shape)} does not match [B,{self.in_chans},{self.patch_embed.img_size[0]},{self.patch_embed.img_size[1]}]")
+        if x.dtype != f32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        self._sync_weights()
+        scales = self._draw_drop_scales(x.shape[0], x.device)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist):
+            return _ViTFunction.apply(x, self, scales, *self._plist)
+        outs, _ = self._forward_impl(x, scales, save=False)
+        return outs[0] if len(outs) == 1 else tuple(outs)
+
+    def _forward_impl(self, img, scales, save):
+        B = img.shape[0]
+        N, D, H, npre, P = self.num_tokens, self.embed_dim, self.num_heads, self.num_prefix_tokens, self.num_patches
+        M = B * N
+        wb = self._wb
+        scale = 64 ** -0.5
+        patches = ops.im2col_patches(img, self.patch_size)
+        x = torch.empty((M, D), dtype=bf16, device=img.device)
+        ops.gemm_nt(patches, wb["patch_embed.proj.weight"], epilogue=EPI_PATCH, bias=self.patch_embed.proj.bias, out=x,
+                    pos=self._pos2d, patches=P, prefix=npre)
+        ops.prefix_tokens_fwd(self._tokens, self._pos2d, x, B, N, D, npre)
+        layers = []
+        for i, blk in enumerate(self.blocks):
+            s1, s2 = scales[i]
+            pre = f"blocks.{i}."
+            y1, m1, r1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+            qkv = ops.gemm_nt(y1, wb[pre + "attn.qkv.weight"], epilogue=EPI_BIAS, bias=blk.attn.qkv.bias)
+            o, lse = ops.attention_fwd(qkv, B, N, H, scale)
+            x2 = ops.gemm_nt(o, wb[pre + "attn.proj.weight"], epilogue=EPI_BIAS_RES, bias=blk.attn.proj.bias, res=x,
+                             rowscale=s1, rows_per_group=N)
+            y2, m2, r2 = ops.layernorm_fwd(x2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            a = torch.empty((M, blk.mlp.fc1.out_features), dtype=bf16, device=img.device)
+            h = ops.gemm_nt(y2, wb[pre + "mlp.fc1.weight"], epilogue=EPI_BIAS_GELU, bias=blk.mlp.fc1.bias, out2=a)
+            x3 = ops.gemm_nt(a, wb[pre + "mlp.fc2.weight"], epilogue=EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x2,
+                             rowscale=s2, rows_per_group=N)
+            if save:
+                layers.append((x, m1, r1, y1, qkv, o, lse, x2, m2, r2, y2, h, a, s1, s2))
+            x = x3
+        tail = {}
+        if self.global_pool == "avg":
+            pooled = ops.pool_avg_fwd(x, B, N, D, npre)
+            f, mf, rf = ops.layernorm_fwd(pooled, self.fc_norm.weight, self.fc_norm.bias, self.fc_norm.eps)
+            logits = ops.gemm_nt(f, wb["head.weight"], epilogue=EPI_BIAS_F32, bias=self.head.bias)
+            outs = [logits]
+            tail = dict(pooled=pooled, f=f, mf=mf, rf=rf)
+        else:
+            c = ops.gather_rows(x, B, N, D, 0)
+            f, mf, rf = ops.layernorm_fwd(c, self.norm.weight, self.norm.bias, self.norm.eps)
+            logits = ops.gemm_nt(f, wb["head.weight"], epilogue=EPI_BIAS_F32, bias=self.head.bias)
+            outs = [logits]
+            tail = dict(c=c, f=f, mf=mf, rf=rf)
+            if self.distilled:
+                c2 = ops.gather_rows(x, B, N, D, 1)
+                f2, mf2, rf2 = ops.layernorm_fwd(c2, self.norm.weight, self.norm.bias, self.norm.eps)
+                logits2 = ops.gemm_nt(f2, wb["head_dist.weight"], epilogue=EPI_BIAS_F32, bias=self.head_dist.bias)
+                tail.update(c2=c2, f2=f2, mf2=mf2, rf2=rf2)
+                if self.distilled_training and self.training:
+                    outs = [logits, logits2]                                 # deit.py:114-116
+                    tail["mode"] = "both"
+                else:
+                    outs = [(logits + logits2) / 2]                          # deit.py:119
+                    tail["mode"] = "mean"
+        saved = dict(B=B, patches=patches, layers=layers, tail=tail) if save else None
+        return outs, saved
+
+    # --------------------------------------------------------------------------------------------- backward
+    def _backward_impl(self, saved, douts):
+        B = saved["B"]
+        N, D, npre = self.num_tokens, self.embed_dim, self.num_prefix_tokens
+        H = self.num_heads
+        M = B * N
+        wb, wt, g, ws = self._wb, self._wt, self._gview, self._ws
+        scale = 64 ** -0.5
+        # grads: overwrite unless a previous backward since the last zero_grad already wrote the buffer
+        acc = self._grad_valid and all(p.grad is not None for p in self._plist)
+        tail = saved["tail"]
+
+        def head_bwd(dlog, f, wname, bname, acc_):
+            dl = ops.cast_f32_to_bf16(dlog.contiguous())
+            ops.gemm_tn(dl, f, g[wname], dbias=g[bname], accumulate=acc_, ws=ws)
+            return ops.gemm_nt(dl, wt[wname])                               # [B, D]
+
+        if self.global_pool == "avg":
+            df = head_bwd(douts[0], tail["f"], "head.weight", "head.bias", acc)
+            dpooled = ops.layernorm_bwd(df, tail["pooled"], tail["mf"], tail["rf"], self.fc_norm.weight, g["fc_norm.weight"],
+                                        g["fc_norm.bias"], accumulate=acc, ws=ws)
+            dx = ops.pool_avg_bwd(dpooled, B, N, D, npre)
+        else:
+            if self.distilled:
+                if tail["mode"] == "both":
+                    d1 = douts[0] if douts[0] is not None else torch.zeros_like(douts[1])
+                    d2 = douts[1] if douts[1] is not None else torch.zeros_like(douts[0])
+                else:
+                    d1 = d2 = douts[0] * 0.5
+            else:
+                d1 = douts[0]
+            df = head_bwd(d1, tail["f"], "head.weight", "head.bias", acc)
+            dc = ops.layernorm_bwd(df, tail["c"], tail["mf"], tail["rf"], self.norm.weight, g["norm.weight"], g["norm.bias"],
+                                   accumulate=acc, ws=ws)
+            dx = torch.empty((M, D), dtype=bf16, device=dc.device)
+            ops.scatter_rows(dc, dx, B, N, D, 0, True)
+            if self.distilled:
+                df2 = head_bwd(d2, tail["f2"], "head_dist.weight", "head_dist.bias", acc)
+                dc2 = ops.layernorm_bwd(df2, tail["c2"], tail["mf2"], tail["rf2"], self.norm.weight, g["norm.weight"],
+                                        g["norm.bias"], accumulate=True, ws=ws)
+                ops.scatter_rows(dc2, dx, B, N, D, 1, False)
+        hook = self._grad_ready_hook
+        if hook is not None:
+            hook(self._head_end, False)
+
+        layers = saved["layers"]
+        for i in reversed(range(self.depth)):
+            blk = self.blocks[i]
+            pre = f"blocks.{i}."
+            (x, m1, r1, y1, qkv, o, lse, x2, m2, r2, y2, h, a, s1, s2) = layers[i]
+            layers[i] = None
+            dx_in = dx
+            # ---- MLP branch: x3 = x2 + s2 * fc2(gelu(fc1(ln2(x2))))
+            dout = ops.rowscale(dx, s2, N) if s2 is not None else dx
+            ops.gemm_tn(dout, a, g[pre + "mlp.fc2.weight"], dbias=g[pre + "mlp.fc2.bias"], accumulate=acc, ws=ws)
+            dh = ops.gemm_nt(dout, wt[pre + "mlp.fc2.weight"], epilogue=EPI_DGELU, aux=h)
+            ops.gemm_tn(dh, y2, g[pre + "mlp.fc1.weight"], dbias=g[pre + "mlp.fc1.bias"], accumulate=acc, ws=ws)
+            dy2 = ops.gemm_nt(dh, wt[pre + "mlp.fc1.weight"])
+            del dh
+            dx2 = ops.layernorm_bwd(dy2, x2, m2, r2, blk.norm2.weight, g[pre + "norm2.weight"], g[pre + "norm2.bias"], dres=dx,
+                                    accumulate=acc, ws=ws)
+            # ---- attention branch: x2 = x + s1 * proj(attn(qkv(ln1(x))))
+            dout = ops.rowscale(dx2, s1, N) if s1 is not None else dx2
+            ops.gemm_tn(dout, o, g[pre + "attn.proj.weight"], dbias=g[pre + "attn.proj.bias"], accumulate=acc, ws=ws)
+            do = ops.gemm_nt(dout, wt[pre + "attn.proj.weight"])
+            dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, scale, ws=ws)
+            ops.gemm_tn(dqkv, y1, g[pre + "attn.qkv.weight"], dbias=g[pre + "attn.qkv.bias"], accumulate=acc, ws=ws)
+            dy1 = ops.gemm_nt(dqkv, wt[pre + "attn.qkv.weight"])
+            del dqkv
+            dx = ops.layernorm_bwd(dy1, x, m1, r1, blk.norm1.weight, g[pre + "norm1.weight"], g[pre + "norm1.bias"], dres=dx2,
+                                   accumulate=acc, ws=ws)
+            if self._bwd_taps is not None:       # tests: the gradients entering / between / leaving the two half-blocks
+                self._bwd_taps[i] = dict(dx_in=dx_in, dx2=dx2, dx=dx, x=x, x2=x2)
+            if hook is not None:
+                hook(self._layer_end[i], False)
+
+        # ---- embedding: x0[b, t] = (t < prefix ? token_t : patches @ Wp^T + bp) + pos[t]
+        ops.pos_tokens_bwd(dx, self._gpos2d, self._gtokens, B, N, D, npre, accumulate=acc)
+        dxp = ops.slice_tokens(dx, B, N, D, npre)
+        ops.gemm_tn(dxp, saved["patches"], g["patch_embed.proj.weight"].view(D, -1), dbias=g["patch_embed.proj.bias"],
+                    accumulate=acc, ws=ws)
+        for n, p in zip(self._pnames, self._plist):
+            if p.grad is None or p.grad.data_ptr() != self._gview[n].data_ptr():
+                p.grad = self._gview[n]
+        self._grad_valid = True
+        if hook is not None:
+            hook(self._total, True)
+
+
+# ------------------------------------------------------------------------------------------------- registry
+# name -> constructor defaults (models/vision_transformer.py:2690-2860, models/my_vit.py:84-165, models/deit.py:306-314)
+_MODEL_CFGS = {
+    "vit_tiny_patch16_224": dict(embed_dim=192, depth=12, num_heads=3, img_size=224),
+    "vit_small_patch16_224": dict(embed_dim=384, depth=12, num_heads=6, img_size=224),
+    "vit_base_patch16_224": dict(embed_dim=768, depth=12, num_heads=12, img_size=224),
+    "vit_base_patch16_384": dict(embed_dim=768, depth=12, num_heads=12, img_size=384),
+    "vit_large_patch16_224": dict(embed_dim=1024, depth=24, num_heads=16, img_size=224),
+    "my_vit_mini": dict(embed_dim=144, depth=12, num_heads=3, img_size=224),
+    "my_vit_ti": dict(embed_dim=192, depth=12, num_heads=3, img_size=224),
+    "my_vit_xs": dict(embed_dim=288, depth=12, num_heads=4, img_size=224),
+    "my_vit_s": dict(embed_dim=384, depth=12, num_heads=6, img_size=224),
+    "my_vit_b": dict(embed_dim=768, depth=12, num_heads=12, img_size=224),
+    "my_vit_l": dict(embed_dim=1024, depth=24, num_heads=16, img_size=224),
+    "deit_tiny_distilled_patch16_224": dict(embed_dim=192, depth=12, num_heads=3, img_size=224, distilled=True),
+    "deit_small_distilled_patch16_224": dict(embed_dim=384, depth=12, num_heads=6, img_size=224, distilled=True),
+    "deit_base_distilled_patch16_224": dict(embed_dim=768, depth=12, num_heads=12, img_size=224, distilled=True),
+}
+
+
+def list_models():
+    return sorted(_MODEL_CFGS)
+
+
+def is_model(name: str) -> bool:
+    return name in _MODEL_CFGS
+
+
+def create_model(model_name: str, pretrained: bool = False, pretrained_cfg=None, pretrained_cfg_overlay=None,
+                 checkpoint_path: Optional[str] = None, cache_dir=None, scriptable=None, exportable=None, no_jit=None,
+                 **kwargs) -> nn.Module:
+    """Same call contract as the reference's models.create_model (models/_factory.py:46-155): None-valued kwargs are
+    dropped (:108), a '.tag' suffix on the name is ignored for construction (:130), an unknown name raises
+    RuntimeError('Unknown model (name)') (:140).  pretrained=True is refused: there is no network (the reference only
+    ever passes pretrained=False, main.py:645, test_kd.py:25)."""
+    kwargs = {k: v for k, v in kwargs.items() if v is not None}
+    name = model_name.split(".", 1)[0]
+    if not is_model(name):
+        raise RuntimeError("Unknown model (%s)" % name)
+    if pretrained:
+        raise RuntimeError("pretrained weights cannot be downloaded in this build (no network); pass pretrained=False "
+                           "and load a local checkpoint with checkpoint_path= or load_state_dict")
+    cfg = dict(_MODEL_CFGS[name])
+    cfg.update(kwargs)
+    model = VisionTransformer(patch_size=16, **cfg)
+    if checkpoint_path:
+        sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        for key in ("model", "module", "state_dict"):
+            if isinstance(sd, dict) and key in sd:
+                sd = sd[key]
+                break
+        model.load_state_dict(sd)
+    return model
