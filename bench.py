@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the ViT-B/16 224px bf16 training step on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one synthetic batch: forward, label-smoothing CE, backward, gradient
+all-reduce (N > 1), fused AdamW - driven by this package's engine.train_one_epoch, i.e. the same loop a user of the
+reference's engine.train_one_epoch would run.  Per-GPU batch is fixed at 512 (global 4096 at 8 GPUs, the reference
+recipe, run_train.sh:14-15), so scaling is weak.  Inputs are generated on the GPU before the timed region.
+Prints ONE JSON line on stdout (rank 0); everything else goes to stderr.
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch
+import torch.distributed as dist
+
+FLOP_PER_IMAGE = {"vit_base_patch16_224": 105.38e9}          # train = 6 x forward MACs, GEMM + attention contractions
+GEMM_FLOP_PER_IMAGE = {"vit_base_patch16_224": 101.09e9}     # the linears/patch/head share (attention products: 4.29e9)
+PEAK_BF16_TFLOPS = 2500.0                                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class SyntheticLoader:
+    """K identical-shape batches that already live in HBM (generated once per rank with seed + rank)."""
+
+    def __init__(self, samples, targets, n):
+        self.samples, self.targets, self.n = samples, targets, n
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for _ in range(self.n):
+            yield self.samples, self.targets
+
+
+def cpu_baseline(batch=16, steps=2, threads=None):
+    """The oracle's reference-semantics fp32 train step (engine.py:257-274 restated) on this box's host cores."""
+    from oracle import ref_engine, ref_ops
+    from oracle.ref_vit import create_ref_model
+    threads = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = create_ref_model("vit_base_patch16_224", num_classes=1000, global_pool="avg", drop_path_rate=0.1)
+    opt = ref_engine.make_optimizer(model, 4e-3, 0.05)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, 3, 224, 224, generator=g)
+    y = torch.randint(0, 1000, (batch,), generator=g)
+    crit = lambda o, t: ref_ops.label_smoothing_ce(o, t, 0.1)
+    ref_engine.ref_train_one_epoch(model, crit, [(x, y)], opt)                      # warm-up
+    t0 = time.time()
+    ref_engine.ref_train_one_epoch(model, crit, [(x, y)] * steps, opt)
+    dt = time.time() - t0
+    return {"value": batch * steps / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"ViT-B/16 224px fp32 CPU oracle train step (fwd+bwd+AdamW), batch {batch}, {steps} timed steps after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--model", default="vit_base_patch16_224")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP kernels are the only implementation of the hot path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
+
+    from vision_transformers_torch_xla_amd import engine, ops, optim_factory, utils
+    from vision_transformers_torch_xla_amd.dp import DistributedDataParallel
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+
+    torch.manual_seed(0)                                       # identical init on every rank (plus rank-0 broadcast)
+    core = create_model(args.model, pretrained=False, num_classes=1000, global_pool="avg", drop_path_rate=0.1).to(device)
+    model = DistributedDataParallel(core, device_ids=[local]) if world > 1 else core
+
+    class OptArgs:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 4e-3, 0.05, 1e-8, None
+    optimizer = optim_factory.create_optimizer(OptArgs, core)
+    criterion = LabelSmoothingCrossEntropy(0.1)
+    total_steps = args.warmup + args.steps
+    lr_sched = utils.cosine_scheduler(4e-3, 1e-6, 1, total_steps, warmup_steps=max(1, args.warmup), warmup_epochs=1)
+    wd_sched = utils.cosine_scheduler(0.05, 0.05, 1, total_steps)
+
+    g = torch.Generator(device=device).manual_seed(0 + rank)    # main.py:405: seed + rank
+    samples = torch.randn(args.batch, 3, 224, 224, generator=g, device=device)
+    targets = torch.randint(0, 1000, (args.batch,), generator=g, device=device)
+
+    def run(nsteps, start):
+        with contextlib.redirect_stdout(sys.stderr):
+            return engine.train_one_epoch(model, criterion, SyntheticLoader(samples, targets, nsteps), optimizer, device, 0, None, 0,
+                                          None, None, start_steps=start, lr_schedule_values=lr_sched, wd_schedule_values=wd_sched,
+                                          num_training_steps_per_epoch=nsteps, update_freq=1, log_freq=10)
+
+    run(args.warmup, 0)
+    want_roof = not args.no_roofline
+    if want_roof:
+        ops.prof_reset()
+        ops.prof_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if want_roof:
+        ops.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * args.batch * args.steps / elapsed
+        result = {
+            "metric": "images/sec (whole node) ViT-B/16 224px bf16", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} train step (fwd + label-smoothing CE + bwd + grad all-reduce + AdamW), "
+                                   f"224x224 synthetic randn batches resident in HBM, drop_path 0.1",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "loss_last": stats.get("loss")},
+            "step_tflops_per_gpu": round(FLOP_PER_IMAGE.get(args.model, 0) * args.batch / (ms * 1e-3) / 1e12, 1),
+        }
+        if want_roof:
+            nt_ms, nt_fl, nt_n = ops.prof_read(ops.PROF_GEMM_NT)
+            tn_ms, tn_fl, tn_n = ops.prof_read(ops.PROF_GEMM_TN)
+            ach = nt_fl / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else 0.0
+            result["roofline"] = {
+                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32; all epilogue instantiations: forward linears + data gradients)",
+                "launches": nt_n, "avg_launch_ms": round(nt_ms / max(nt_n, 1), 4),
+                "flop_per_launch_avg": round(nt_fl / max(nt_n, 1) / 1e9, 2),
+                "also": {"kernel": "gemm_tn_kernel (weight gradients)", "achieved": round(tn_fl / (tn_ms * 1e-3) / 1e12, 1) if tn_ms > 0 else 0.0,
+                         "launches": tn_n, "avg_launch_ms": round(tn_ms / max(tn_n, 1), 4)},
+                "gemm_share_of_step": round((nt_ms + tn_ms) / (elapsed * 1e3), 3),
+            }
+            ops.prof_reset()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
+                log(f"[bench] cpu baseline failed: {e!r}")
+                result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,8 +46,13 @@ const char* vitk_last_error(void);
 
 /* ---- profiling of the dominant kernel family (GEMM): per-launch hipEvent brackets on the launch stream.
  * No counterpart in the reference (it has no profiling hooks, engine.py:157-195 only keeps wall-clock deltas). */
+#define VITK_PROF_ALL (-1)
+#define VITK_PROF_GEMM_NT 0
+#define VITK_PROF_GEMM_TN 1
 int vitk_prof_enable(int on);                                  /* 1: bracket every GEMM launch with events */
-int vitk_prof_read(double* total_ms, double* total_flop, int64_t* launches);  /* syncs the events, then resets */
+/* sums over the recorded launches of one kind (or all): waits for their events; records stay until vitk_prof_reset() */
+int vitk_prof_read(int kind, double* total_ms, double* total_flop, int64_t* launches);
+int vitk_prof_reset(void);
 
 /* ---- LayerNorm.  Replaces timm LayerNorm = F.layer_norm(x,(D,),w,b,eps=1e-6) used at
  * models/vision_transformer.py:148,163,530,616.  x,y bf16 [M,D]; gamma,beta fp32 [D]; mean,rstd fp32 [M]. D%8==0, D<=1024 */

@@ -8,6 +8,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+# torch must be imported before libvitk.so is dlopen'ed: both need libamdhip64, and the process has to end up with ONE HIP
+# runtime (the one torch ships and initialises); loading ours first pulls in /opt/rocm's copy and the device is not found.
+import torch  # noqa: F401
+
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libvitk.so"
 
 _p = C.c_void_p
@@ -21,7 +25,8 @@ SIGNATURES = {
     "vitk_version": (_i, []),
     "vitk_last_error": (C.c_char_p, []),
     "vitk_prof_enable": (_i, [_i]),
-    "vitk_prof_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "vitk_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "vitk_prof_reset": (_i, []),
     "vitk_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "vitk_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "vitk_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),

@@ -24,15 +24,16 @@ int vitk_check_launch(const char* what) {
 }
 
 // ---- profiling: one (start, stop) event pair per bracketed launch, kept until vitk_prof_read()
-struct ProfRec { hipEvent_t a, b; double flop; };
+struct ProfRec { hipEvent_t a, b; double flop; int kind; };
 static std::mutex g_prof_mu;
 static int g_prof_on = 0;
 static std::vector<ProfRec> g_prof;
 
-bool vitk_prof_begin(void* stream, double flop) {
+bool vitk_prof_begin(void* stream, double flop, int kind) {
     if (!g_prof_on) return false;
     ProfRec r;
     r.flop = flop;
+    r.kind = kind;
     if (hipEventCreate(&r.a) != hipSuccess) return false;
     if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return false; }
     (void)hipEventRecord(r.a, (hipStream_t)stream);
@@ -56,22 +57,30 @@ int vitk_prof_enable(int on) {
     return VITK_OK;
 }
 
-int vitk_prof_read(double* total_ms, double* total_flop, int64_t* launches) {
+int vitk_prof_read(int kind, double* total_ms, double* total_flop, int64_t* launches) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     double ms = 0, fl = 0;
     int64_t n = 0;
     for (auto& r : g_prof) {
+        if (kind != VITK_PROF_ALL && r.kind != kind) continue;
         float t = 0;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
             ms += t; fl += r.flop; ++n;
         }
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flop) *total_flop = fl;
+    if (launches) *launches = n;
+    return VITK_OK;
+}
+
+int vitk_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
-    if (total_ms) *total_ms = ms;
-    if (total_flop) *total_flop = fl;
-    if (launches) *launches = n;
     return VITK_OK;
 }
 

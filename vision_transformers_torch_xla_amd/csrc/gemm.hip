@@ -15,7 +15,7 @@
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-bool vitk_prof_begin(void* stream, double flop);
+bool vitk_prof_begin(void* stream, double flop, int kind);
 void vitk_prof_end(void* stream);
 
 #define GBM 128
@@ -405,7 +405,7 @@ int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ld
     p.tiles_n = (N + GBN - 1) / GBN;
     p.num_tiles = tiles_m * p.tiles_n;
     hipStream_t s = (hipStream_t)stream;
-    const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K);
+    const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_NT);
     switch (epilogue) {
         case VITK_EPI_PLAIN: gemm_nt_kernel<VITK_EPI_PLAIN><<<p.num_tiles, 256, 0, s>>>(p); break;
         case VITK_EPI_BIAS: gemm_nt_kernel<VITK_EPI_BIAS><<<p.num_tiles, 256, 0, s>>>(p); break;
@@ -451,7 +451,7 @@ int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int l
     p.tiles_k = (K + GBN - 1) / GBN;
     dim3 grid(tiles_n * p.tiles_k, splits);
     hipStream_t s = (hipStream_t)stream;
-    const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K);
+    const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_TN);
     if (dbias) gemm_tn_kernel<true><<<grid, 256, 0, s>>>(p);
     else gemm_tn_kernel<false><<<grid, 256, 0, s>>>(p);
     if (pr) vitk_prof_end(stream);

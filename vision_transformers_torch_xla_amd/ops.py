@@ -321,8 +321,16 @@ def prof_enable(on: bool):
     check(_lib.load().vitk_prof_enable(int(on)), "prof_enable")
 
 
-def prof_read():
+PROF_ALL, PROF_GEMM_NT, PROF_GEMM_TN = -1, 0, 1
+
+
+def prof_read(kind=PROF_ALL):
+    """(total ms, total flop, launches) of the event-bracketed GEMM launches of one kind"""
     import ctypes as C
     ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
-    check(_lib.load().vitk_prof_read(C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
+    check(_lib.load().vitk_prof_read(kind, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
     return ms.value, fl.value, n.value
+
+
+def prof_reset():
+    check(_lib.load().vitk_prof_reset(), "prof_reset")
