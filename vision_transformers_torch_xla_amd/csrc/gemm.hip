@@ -12,6 +12,7 @@
 // The MFMA operands are swapped (first operand = the matrix whose rows become output columns) so that each
 // lane ends up holding 4 consecutive output columns of one row: 8-byte (bf16) / 16-byte (fp32) stores.
 #include "common.h"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -55,6 +56,43 @@ static __device__ __forceinline__ void load4_bf16(const bf16_t* p, float (&v)[4]
     const uint2 r = *reinterpret_cast<const uint2*>(p);
     v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
     v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+
+// Fused epilogue on 4 consecutive output columns n..n+3 of row m held by one lane (fp32 accumulators in v).
+template <int EPI>
+static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float (&v)[4], int m, int n, int orow, float rs,
+                                                   const float* posrow) {
+    if (EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (EPI == VITK_EPI_PLAIN || EPI == VITK_EPI_BIAS) {
+        store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+    } else if (EPI == VITK_EPI_BIAS_F32) {
+        *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (EPI == VITK_EPI_BIAS_GELU) {
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = gelu_erf(bf2f(f2bf(v[j])));
+        store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+        store4_bf16(p.out2 + (size_t)m * p.ldout2 + n, a);
+    } else if (EPI == VITK_EPI_BIAS_RES) {
+        float r[4];
+        load4_bf16(p.res + (size_t)m * p.ldres + n, r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = r[j] + rs * v[j];
+        store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+    } else if (EPI == VITK_EPI_PATCH) {
+        const float4 q4 = *reinterpret_cast<const float4*>(posrow + n);
+        v[0] += q4.x; v[1] += q4.y; v[2] += q4.z; v[3] += q4.w;
+        store4_bf16((bf16_t*)p.C + (size_t)orow * p.ldc + n, v);
+    } else if (EPI == VITK_EPI_DGELU) {
+        float h[4];
+        load4_bf16(p.aux + (size_t)m * p.ldaux + n, h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= dgelu_erf(h[j]);
+        store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+    }
 }
 
 template <int EPI>
@@ -166,37 +204,134 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTParams p) {
             const int n = n0 + wn * 64 + tn * 16 + 4 * lg;
             if (n >= p.N) continue;
             float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-            if (EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU) {
-                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            nt_epilogue<EPI>(p, v, m, n, orow, rs, posrow);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// gemm_nt, large-tile variant: 256x256 block tile, 8 waves (2 x 4, each 128x64 = 8x4 MFMA tiles, 128 accumulator
+// registers), BK = 64.  Operands go global -> LDS directly (global_load_lds, 16 B per lane, no VGPR staging) into a
+// double-buffered 128 KB LDS image; the loads of K-step t+1 are in flight while the MFMAs of step t run, one barrier per
+// K-step.  The direct load writes LDS lane-linearly (wave base + lane*16), so the bank-conflict XOR swizzle is applied
+// to the per-lane SOURCE chunk and again on the fragment read.  Needs K % 64 == 0 (no zero-fill on this path).
+#define LBM 256
+#define LBN 256
+#define LTILE (256 * GBK)            // elements per operand tile
+
+static __device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmNTParams p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t lsm[];   // [2 buffers][A tile | B tile]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const int tile = xcd_remap(blockIdx.x, p.num_tiles);
+    const int m0 = (tile / p.tiles_n) * LBM;
+    const int n0 = (tile % p.tiles_n) * LBN;
+
+    // staging: wave w, instruction j covers rows (w*4+j)*8 .. +7 of the tile; lane -> row += lane/8, position lane%8,
+    // which receives source chunk (lane%8) ^ (row&7)
+    const int srow = lane >> 3, spos = lane & 7;
+    const bf16_t* gA[4];
+    const bf16_t* gB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + srow;
+        int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+        int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+        const int ch = spos ^ (row & 7);
+        gA[j] = p.A + (size_t)gm * p.lda + ch * 8;
+        gB[j] = p.B + (size_t)gn * p.ldb + ch * 8;
+    }
+    const int lds_stage = wave * 4 * 8 * GBK;     // element offset of this wave's first 8-row group inside a tile
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (elements) inside a tile: row*64 + ((chunk ^ (row&7)) << 3); row&7 == lr&7 for every tile row
+    int offA[2], offB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int x = (((ks * 4 + lg) ^ (lr & 7)) << 3);
+        offA[ks] = (wm * 128 + lr) * GBK + x;
+        offB[ks] = (wn * 64 + lr) * GBK + x;
+    }
+
+    const int nk = p.K / GBK;
+    {
+        bf16_t* dA = lsm + lds_stage;
+        bf16_t* dB = lsm + LTILE + lds_stage;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(gA[j], dA + j * 8 * GBK);
+            glds16(gB[j], dB + j * 8 * GBK);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const bf16_t* cA = lsm + (kt & 1) * 2 * LTILE;
+        const bf16_t* cB = cA + LTILE;
+        if (kt + 1 < nk) {
+            bf16_t* dA = lsm + ((kt + 1) & 1) * 2 * LTILE + lds_stage;
+            bf16_t* dB = dA + LTILE;
+            const int kofs = (kt + 1) * GBK;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                glds16(gA[j] + kofs, dA + j * 8 * GBK);
+                glds16(gB[j] + kofs, dB + j * 8 * GBK);
             }
-            if (EPI == VITK_EPI_PLAIN || EPI == VITK_EPI_BIAS) {
-                store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
-            } else if (EPI == VITK_EPI_BIAS_F32) {
-                *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if (EPI == VITK_EPI_BIAS_GELU) {
-                float a[4];
+        }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = gelu_erf(bf2f(f2bf(v[j])));
-                store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
-                store4_bf16(p.out2 + (size_t)m * p.ldout2 + n, a);
-            } else if (EPI == VITK_EPI_BIAS_RES) {
-                float r[4];
-                load4_bf16(p.res + (size_t)m * p.ldres + n, r);
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[8], fb[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = r[j] + rs * v[j];
-                store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
-            } else if (EPI == VITK_EPI_PATCH) {
-                const float4 q4 = *reinterpret_cast<const float4*>(posrow + n);
-                v[0] += q4.x; v[1] += q4.y; v[2] += q4.z; v[3] += q4.w;
-                store4_bf16((bf16_t*)p.C + (size_t)orow * p.ldc + n, v);
-            } else if (EPI == VITK_EPI_DGELU) {
-                float h[4];
-                load4_bf16(p.aux + (size_t)m * p.ldaux + n, h);
+            for (int t = 0; t < 8; ++t) fa[t] = *reinterpret_cast<const bf16x8*>(cA + offA[ks] + t * 16 * GBK);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= dgelu_erf(h[j]);
-                store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
-            }
+            for (int t = 0; t < 4; ++t) fb[t] = *reinterpret_cast<const bf16x8*>(cB + offB[ks] + t * 16 * GBK);
+#pragma unroll
+            for (int tm = 0; tm < 8; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[tm][tn], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm) {
+        const int m = m0 + wm * 128 + tm * 16 + lr;
+        if (m >= p.M) continue;
+        float rs = 1.0f;
+        int orow = m;
+        const float* posrow = nullptr;
+        if (EPI == VITK_EPI_BIAS_RES) {
+            if (p.rowscale != nullptr) rs = p.rowscale[m / p.rows_per_group];
+        }
+        if (EPI == VITK_EPI_PATCH) {
+            const int b = m / p.patches, pi = m - b * p.patches;
+            orow = b * (p.patches + p.prefix) + p.prefix + pi;
+            posrow = p.pos + (size_t)(p.prefix + pi) * p.N;
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wn * 64 + tn * 16 + 4 * lg;
+            if (n >= p.N) continue;
+            float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
+            nt_epilogue<EPI>(p, v, m, n, orow, rs, posrow);
         }
     }
 }
@@ -209,10 +344,17 @@ struct GemmTNParams {
     float* colslab;     // [splits][N] or null
     int M, N, K;
     int m_per_split;
+    int tiles, splits_per_xcd;
     int tiles_k;
 };
 
 #define TBM 64   // contraction rows staged per step
+
+// gemm_tn LDS image: [64 m][128 cols] bf16, 256-byte rows = one LDS bank row.  A ds_read_b64_tr_b16 is serviced per
+// 32-lane half = 2 lane groups x 4 rows (m = 8g+q) x 4 eight-byte pieces; unswizzled, the 8 rows hit the same 32 bytes
+// (8-way conflict).  XOR the 16-byte chunk index with 2*(4*((m>>3)&1) + (m&3)): the 8 rows of a half land on 8 disjoint
+// chunk pairs -> conflict-free.
+static __device__ __forceinline__ int tn_swz(int m) { return (((m >> 3) & 1) << 3) | ((m & 3) << 1); }
 
 static __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* lo, const bf16_t* hi) {
     const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)lo);
@@ -230,9 +372,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNParams p) {
     const int lr = lane & 15, lg = lane >> 4;
     const int lq = lr >> 2, lp = lr & 3;
 
-    const int n0 = (blockIdx.x / p.tiles_k) * GBN;
-    const int k0 = (blockIdx.x % p.tiles_k) * GBN;
-    const int split = blockIdx.y;
+    // Blocks are dealt round-robin over the 8 XCDs.  All blocks of one XCD walk the SAME contraction (m) range at about
+    // the same time, tile after tile, so each activation row is fetched from HBM into one L2 only (instead of into all 8):
+    // xcd = bid % 8 owns splits [xcd*spx, (xcd+1)*spx); its blocks take (split, tile) pairs split-major, tile n-major.
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int tile_id = local % p.tiles;
+    const int split = xcd * p.splits_per_xcd + local / p.tiles;
+    const int n0 = (tile_id / p.tiles_k) * GBN;
+    const int k0 = (tile_id % p.tiles_k) * GBN;
     const int ms = split * p.m_per_split;
     int me = ms + p.m_per_split; me = me < p.M ? me : p.M;
 
@@ -254,30 +401,42 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const bool do_colsum = COLSUM && (blockIdx.x % p.tiles_k) == 0;
+    const bool do_colsum = COLSUM && (tile_id % p.tiles_k) == 0;
 
+    // Loads are unconditional, from clamped (always valid) addresses, and nothing consumes a loaded register before the
+    // next step's LDS store: a "valid ? load : 0" select makes hipcc branch around every load and wait for each one in
+    // turn, and an AND placed beside the load makes it wait right there.  Validity travels as one mask word per load
+    // (column in range && row in range), applied at the LDS store.
+    const unsigned cmA = a_col_ok ? ~0u : 0u, cmB = b_col_ok ? ~0u : 0u;
+    unsigned mkA[4], mkB[4];
     auto gload = [&](int mbase) {
+        const bool full = mbase + TBM <= me;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gm = mbase + srow + 16 * i;
-            const bool ok = gm < me;
-            const int gmc = ok ? gm : p.M - 1;      // unconditional load from a valid row, zeroed by value select
-            const u32x4 ta = *reinterpret_cast<const u32x4*>(gA + (size_t)gmc * p.lda);
-            const u32x4 tb = *reinterpret_cast<const u32x4*>(gB + (size_t)gmc * p.ldb);
-            ra[i] = (ok && a_col_ok) ? ta : zero4;
-            rb[i] = (ok && b_col_ok) ? tb : zero4;
+            const bool rok = full || gm < me;
+            const int gmc = rok ? gm : me - 1;
+            ra[i] = *reinterpret_cast<const u32x4*>(gA + (size_t)gmc * p.lda);
+            rb[i] = *reinterpret_cast<const u32x4*>(gB + (size_t)gmc * p.ldb);
+            mkA[i] = rok ? cmA : 0u;
+            mkB[i] = rok ? cmB : 0u;
         }
     };
 
-    gload(ms);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ra[i] = zero4; rb[i] = zero4; mkA[i] = 0u; mkB[i] = 0u; }
+    if (ms < me) gload(ms);
     for (int mb = ms; mb < me; mb += TBM) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = srow + 16 * i;
-            *reinterpret_cast<u32x4*>(&sA[row * GBN + sch * 8]) = ra[i];
-            *reinterpret_cast<u32x4*>(&sB[row * GBN + sch * 8]) = rb[i];
+            const int so = row * GBN + ((sch ^ tn_swz(row)) << 3);
+            const u32x4 va = ra[i] & (u32x4){mkA[i], mkA[i], mkA[i], mkA[i]};
+            const u32x4 vb = rb[i] & (u32x4){mkB[i], mkB[i], mkB[i], mkB[i]};
+            *reinterpret_cast<u32x4*>(&sA[so]) = va;
+            *reinterpret_cast<u32x4*>(&sB[so]) = vb;
             if (do_colsum) {
-                const u32x4 r = ra[i];
+                const u32x4 r = va;
                 colacc[0] += __uint_as_float(r.x << 16); colacc[1] += __uint_as_float(r.x & 0xffff0000u);
                 colacc[2] += __uint_as_float(r.y << 16); colacc[3] += __uint_as_float(r.y & 0xffff0000u);
                 colacc[4] += __uint_as_float(r.z << 16); colacc[5] += __uint_as_float(r.z & 0xffff0000u);
@@ -290,10 +449,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNParams p) {
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
             const int r0 = ks * 32 + 8 * lg + lq;   // rows of the first 4-row block; second block is +4
+            const int sw = tn_swz(r0);               // tn_swz(r0 + 4) == tn_swz(r0)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int ca = wr * 64 + t * 16 + 4 * lp;
-                const int cb = wc * 64 + t * 16 + 4 * lp;
+                // 16-byte chunk index of the lane's 4 columns, swizzled; (lp & 1) picks the 8-byte half of the chunk
+                const int ca = ((((wr * 64 + t * 16) >> 3) + (lp >> 1)) ^ sw) * 8 + (lp & 1) * 4;
+                const int cb = ((((wc * 64 + t * 16) >> 3) + (lp >> 1)) ^ sw) * 8 + (lp & 1) * 4;
                 fa[t] = tr_frag(&sA[r0 * GBN + ca], &sA[(r0 + 4) * GBN + ca]);
                 fb[t] = tr_frag(&sB[r0 * GBN + cb], &sB[(r0 + 4) * GBN + cb]);
             }
@@ -361,13 +522,15 @@ __global__ void reduce_vec_kernel(const float* __restrict__ slab, int splits, in
 }
 
 static int tn_splits(int M, int N, int K) {
+    // a multiple of 8 (one group of splits per XCD); enough (split, tile) pairs per XCD to fill its 32 CUs several
+    // times over, but at least 512 contraction rows per split and at most 4 splits per XCD (slab traffic)
     const int tiles = ((N + GBN - 1) / GBN) * ((K + GBN - 1) / GBN);
-    int s = (1024 + tiles - 1) / tiles;
-    const int max_by_rows = (M + 511) / 512;   // at least 512 contraction rows per split
-    if (s > max_by_rows) s = max_by_rows;
-    if (s > 32) s = 32;
-    if (s < 1) s = 1;
-    return s;
+    int spx = (256 + tiles - 1) / tiles;
+    const int max_by_rows = (M / 8) / 512;
+    if (spx > max_by_rows) spx = max_by_rows;
+    if (spx > 4) spx = 4;
+    if (spx < 1) spx = 1;
+    return 8 * spx;
 }
 
 extern "C" {
@@ -401,19 +564,48 @@ int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ld
     p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16_t*)res; p.ldres = ldres;
     p.rowscale = rowscale; p.rows_per_group = rows_per_group; p.out2 = (bf16_t*)out2; p.ldout2 = ldout2;
     p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pos = pos; p.patches = patches; p.prefix = prefix;
-    const int tiles_m = (M + GBM - 1) / GBM;
-    p.tiles_n = (N + GBN - 1) / GBN;
-    p.num_tiles = tiles_m * p.tiles_n;
     hipStream_t s = (hipStream_t)stream;
+    // large problems with K a multiple of 64 take the 256x256 direct-to-LDS kernel; the 128x128 register-staged kernel
+    // handles K tails (zero fill) and small shapes.  VITK_GEMM_SMALL=1 forces the latter (A/B testing).
+    static const bool force_small = getenv("VITK_GEMM_SMALL") != nullptr;
+    const bool big = !force_small && K % GBK == 0 && M >= 512 && N >= 128;
     const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_NT);
-    switch (epilogue) {
-        case VITK_EPI_PLAIN: gemm_nt_kernel<VITK_EPI_PLAIN><<<p.num_tiles, 256, 0, s>>>(p); break;
-        case VITK_EPI_BIAS: gemm_nt_kernel<VITK_EPI_BIAS><<<p.num_tiles, 256, 0, s>>>(p); break;
-        case VITK_EPI_BIAS_F32: gemm_nt_kernel<VITK_EPI_BIAS_F32><<<p.num_tiles, 256, 0, s>>>(p); break;
-        case VITK_EPI_BIAS_GELU: gemm_nt_kernel<VITK_EPI_BIAS_GELU><<<p.num_tiles, 256, 0, s>>>(p); break;
-        case VITK_EPI_BIAS_RES: gemm_nt_kernel<VITK_EPI_BIAS_RES><<<p.num_tiles, 256, 0, s>>>(p); break;
-        case VITK_EPI_PATCH: gemm_nt_kernel<VITK_EPI_PATCH><<<p.num_tiles, 256, 0, s>>>(p); break;
-        case VITK_EPI_DGELU: gemm_nt_kernel<VITK_EPI_DGELU><<<p.num_tiles, 256, 0, s>>>(p); break;
+    if (big) {
+        p.tiles_n = (N + LBN - 1) / LBN;
+        p.num_tiles = ((M + LBM - 1) / LBM) * p.tiles_n;
+        const size_t smem = (size_t)4 * LTILE * sizeof(bf16_t);
+#define VITK_LAUNCH_BIG(E)                                                                                              \
+    case E: {                                                                                                           \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            if (e != hipSuccess) { vitk_set_error("gemm_nt: cannot set LDS size: %s", hipGetErrorString(e)); return VITK_ELAUNCH; }    \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        gemm_nt256_kernel<E><<<p.num_tiles, 512, smem, s>>>(p);                                                         \
+    } break;
+        switch (epilogue) {
+            VITK_LAUNCH_BIG(VITK_EPI_PLAIN)
+            VITK_LAUNCH_BIG(VITK_EPI_BIAS)
+            VITK_LAUNCH_BIG(VITK_EPI_BIAS_F32)
+            VITK_LAUNCH_BIG(VITK_EPI_BIAS_GELU)
+            VITK_LAUNCH_BIG(VITK_EPI_BIAS_RES)
+            VITK_LAUNCH_BIG(VITK_EPI_PATCH)
+            VITK_LAUNCH_BIG(VITK_EPI_DGELU)
+        }
+#undef VITK_LAUNCH_BIG
+    } else {
+        p.tiles_n = (N + GBN - 1) / GBN;
+        p.num_tiles = ((M + GBM - 1) / GBM) * p.tiles_n;
+        switch (epilogue) {
+            case VITK_EPI_PLAIN: gemm_nt_kernel<VITK_EPI_PLAIN><<<p.num_tiles, 256, 0, s>>>(p); break;
+            case VITK_EPI_BIAS: gemm_nt_kernel<VITK_EPI_BIAS><<<p.num_tiles, 256, 0, s>>>(p); break;
+            case VITK_EPI_BIAS_F32: gemm_nt_kernel<VITK_EPI_BIAS_F32><<<p.num_tiles, 256, 0, s>>>(p); break;
+            case VITK_EPI_BIAS_GELU: gemm_nt_kernel<VITK_EPI_BIAS_GELU><<<p.num_tiles, 256, 0, s>>>(p); break;
+            case VITK_EPI_BIAS_RES: gemm_nt_kernel<VITK_EPI_BIAS_RES><<<p.num_tiles, 256, 0, s>>>(p); break;
+            case VITK_EPI_PATCH: gemm_nt_kernel<VITK_EPI_PATCH><<<p.num_tiles, 256, 0, s>>>(p); break;
+            case VITK_EPI_DGELU: gemm_nt_kernel<VITK_EPI_DGELU><<<p.num_tiles, 256, 0, s>>>(p); break;
+        }
     }
     if (pr) vitk_prof_end(stream);
     return vitk_check_launch("gemm_nt");
@@ -449,7 +641,9 @@ int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int l
     p.m_per_split = mps;
     const int tiles_n = (N + GBN - 1) / GBN;
     p.tiles_k = (K + GBN - 1) / GBN;
-    dim3 grid(tiles_n * p.tiles_k, splits);
+    p.tiles = tiles_n * p.tiles_k;
+    p.splits_per_xcd = splits / 8;
+    dim3 grid(p.tiles * splits);
     hipStream_t s = (hipStream_t)stream;
     const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_TN);
     if (dbias) gemm_tn_kernel<true><<<grid, 256, 0, s>>>(p);
