@@ -136,12 +136,13 @@ int vitk_argmax_rows(const float* logits, int ld, int64_t* idx, int B, int C, vo
 
 /* ---- fused AdamW over a flat fp32 parameter range (torch.optim.AdamW semantics, optim_factory.py:248-249),
  * with bf16 copy-out of the updated weights and optional EMA (timm ModelEma, engine.py:198-202,273-274).
- * p,g,m,v fp32 [n]; p_bf16 may be null; ema may be null. step is the 1-based step count. */
-int vitk_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, float* ema, float ema_decay,
-                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+ * p,g,m,v fp32 [n]; p_bf16 may be null; ema may be null. step is the 1-based step count.  Hyper-parameters are doubles,
+ * as the Python floats of the reference are: 1-beta, bias corrections and lr*weight_decay are formed in double. */
+int vitk_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, float* ema, double ema_decay,
+                    int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                     float grad_scale, void* stream);
 /* ema = decay*ema + (1-decay)*p over a flat fp32 range (timm ModelEma.update, engine.py:198-202,273-274) */
-int vitk_ema_update(float* ema, const float* p, float decay, int64_t n, void* stream);
+int vitk_ema_update(float* ema, const float* p, double decay, int64_t n, void* stream);
 /* g *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) with sumsq[0] read on the device (torch clip_grad_norm_, engine.py:175-177) */
 int vitk_clip_grad_scale(float* g, int64_t n, const float* sumsq, float max_norm, void* stream);
 /* sum of squares of a flat fp32 range -> out[0] (+)=, for clip_grad_norm_ (engine.py:175-177) */

@@ -17,6 +17,7 @@ LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libvitk.so"
 _p = C.c_void_p
 _i = C.c_int
 _f = C.c_float
+_d = C.c_double
 _i64 = C.c_int64
 _sz = C.c_size_t
 
@@ -53,8 +54,8 @@ SIGNATURES = {
     "vitk_xent_soft_fwd_bwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _f, _i, _i, _p]),
     "vitk_kd_kl_fwd_bwd": (_i, [_p, _i, _p, _i, _f, _p, _p, _i, _f, _i, _i, _p]),
     "vitk_argmax_rows": (_i, [_p, _i, _p, _i, _i, _p]),
-    "vitk_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _f, _i64, _f, _f, _f, _f, _f, _i, _f, _p]),
-    "vitk_ema_update": (_i, [_p, _p, _f, _i64, _p]),
+    "vitk_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _d, _i64, _d, _d, _d, _d, _d, _i, _f, _p]),
+    "vitk_ema_update": (_i, [_p, _p, _d, _i64, _p]),
     "vitk_clip_grad_scale": (_i, [_p, _i64, _p, _f, _p]),
     "vitk_sumsq": (_i, [_p, _i64, _p, _i, _p, _sz, _p]),
     "vitk_sumsq_workspace": (_sz, [_i64]),

@@ -46,52 +46,96 @@ static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-static __device__ __forceinline__ void store4_bf16(bf16_t* p, const float (&v)[4]) {
-    uint2 r;
-    r.x = pack2bf(v[0], v[1]);
-    r.y = pack2bf(v[2], v[3]);
-    *reinterpret_cast<uint2*>(p) = r;
+// W (4 or 8) consecutive bf16 <-> fp32
+template <int W>
+static __device__ __forceinline__ void store_bf16(bf16_t* p, const float (&v)[W]) {
+    if (W == 4) {
+        uint2 r;
+        r.x = pack2bf(v[0], v[1]);
+        r.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p) = r;
+    } else {
+        // streaming store: a tile round writes as much as an XCD's whole L2 holds; kept out of it, the weight panel and
+        // the activation panels in use stay resident
+        u32x4 r = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[W - 4], v[W - 3]), pack2bf(v[W - 2], v[W - 1])};
+        __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(p));
+    }
 }
-static __device__ __forceinline__ void load4_bf16(const bf16_t* p, float (&v)[4]) {
-    const uint2 r = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+template <int W>
+static __device__ __forceinline__ void load_bf16(const bf16_t* p, float (&v)[W]) {
+    if (W == 4) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    } else {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+        v[W - 4] = __uint_as_float(r.z << 16); v[W - 3] = __uint_as_float(r.z & 0xffff0000u);
+        v[W - 2] = __uint_as_float(r.w << 16); v[W - 1] = __uint_as_float(r.w & 0xffff0000u);
+    }
+}
+template <int W>
+static __device__ __forceinline__ void add_f32(const float* q, float (&v)[W]) {
+#pragma unroll
+    for (int i = 0; i < W; i += 4) {
+        const float4 b4 = *reinterpret_cast<const float4*>(q + i);
+        v[i] += b4.x; v[i + 1] += b4.y; v[i + 2] += b4.z; v[i + 3] += b4.w;
+    }
 }
 
-// Fused epilogue on 4 consecutive output columns n..n+3 of row m held by one lane (fp32 accumulators in v).
+// Fused epilogue on W (4 or 8) consecutive output columns n..n+W-1 of row m held by one lane (fp32 accumulators in v).
+// side operand of an epilogue (residual for BIAS_RES, pre-activation for DGELU): W bf16 of row m starting at column n
 template <int EPI>
-static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float (&v)[4], int m, int n, int orow, float rs,
-                                                   const float* posrow) {
+static __device__ __forceinline__ const bf16_t* nt_side_ptr(const GemmNTParams& p, int m, int n) {
+    return EPI == VITK_EPI_BIAS_RES ? p.res + (size_t)m * p.ldres + n : p.aux + (size_t)m * p.ldaux + n;
+}
+static __device__ __forceinline__ void unpack_bf16x8(const u32x4 r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+template <int EPI, int W>
+static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float (&v)[W], int m, int n, int orow, float rs,
+                                                   const float* posrow, const float* side = nullptr,
+                                                   const float* bias_regs = nullptr) {
     if (EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU) {
-        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        if (bias_regs) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[j] += bias_regs[j];
+        } else {
+            add_f32<W>(p.bias + n, v);
+        }
     }
     if (EPI == VITK_EPI_PLAIN || EPI == VITK_EPI_BIAS) {
-        store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+        store_bf16<W>((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
     } else if (EPI == VITK_EPI_BIAS_F32) {
-        *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int i = 0; i < W; i += 4)
+            *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
     } else if (EPI == VITK_EPI_BIAS_GELU) {
-        float a[4];
+        float a[W];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = gelu_erf(bf2f(f2bf(v[j])));
-        store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
-        store4_bf16(p.out2 + (size_t)m * p.ldout2 + n, a);
+        for (int j = 0; j < W; ++j) a[j] = gelu_erf(bf2f(f2bf(v[j])));
+        store_bf16<W>((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+        store_bf16<W>(p.out2 + (size_t)m * p.ldout2 + n, a);
     } else if (EPI == VITK_EPI_BIAS_RES) {
-        float r[4];
-        load4_bf16(p.res + (size_t)m * p.ldres + n, r);
+        float r[W];
+        if (side == nullptr) load_bf16<W>(p.res + (size_t)m * p.ldres + n, r);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = r[j] + rs * v[j];
-        store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+        for (int j = 0; j < W; ++j) v[j] = (side ? side[j] : r[j]) + rs * v[j];
+        store_bf16<W>((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
     } else if (EPI == VITK_EPI_PATCH) {
-        const float4 q4 = *reinterpret_cast<const float4*>(posrow + n);
-        v[0] += q4.x; v[1] += q4.y; v[2] += q4.z; v[3] += q4.w;
-        store4_bf16((bf16_t*)p.C + (size_t)orow * p.ldc + n, v);
+        add_f32<W>(posrow + n, v);
+        store_bf16<W>((bf16_t*)p.C + (size_t)orow * p.ldc + n, v);
     } else if (EPI == VITK_EPI_DGELU) {
-        float h[4];
-        load4_bf16(p.aux + (size_t)m * p.ldaux + n, h);
+        float h[W];
+        if (side == nullptr) load_bf16<W>(p.aux + (size_t)m * p.ldaux + n, h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= dgelu_erf(h[j]);
-        store4_bf16((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+        for (int j = 0; j < W; ++j) v[j] *= dgelu_erf(side ? side[j] : h[j]);
+        store_bf16<W>((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
     }
 }
 
@@ -204,60 +248,84 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTParams p) {
             const int n = n0 + wn * 64 + tn * 16 + 4 * lg;
             if (n >= p.N) continue;
             float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-            nt_epilogue<EPI>(p, v, m, n, orow, rs, posrow);
+            nt_epilogue<EPI, 4>(p, v, m, n, orow, rs, posrow);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// gemm_nt, large-tile variant: 256x256 block tile, 8 waves (2 x 4, each 128x64 = 8x4 MFMA tiles, 128 accumulator
-// registers), BK = 64.  Operands go global -> LDS directly (global_load_lds, 16 B per lane, no VGPR staging) into a
-// double-buffered 128 KB LDS image; the loads of K-step t+1 are in flight while the MFMAs of step t run, one barrier per
-// K-step.  The direct load writes LDS lane-linearly (wave base + lane*16), so the bank-conflict XOR swizzle is applied
-// to the per-lane SOURCE chunk and again on the fragment read.  Needs K % 64 == 0 (no zero-fill on this path).
+// gemm_nt, large-tile persistent variant.  One 512-thread workgroup per CU walks over 256x256 output tiles; 8 waves
+// (2 x 4), each a 128x64 sub-tile = 8x4 MFMA tiles = 128 accumulator registers; BK = 64.
+//  * Operands go global -> LDS directly (LDS-DMA, 16 B per lane, no register stop) into a double-buffered 128 KB image.
+//    The DMA writes LDS lane-linearly (wave base + 16*lane), so the bank-conflict XOR swizzle is applied to the per-lane
+//    SOURCE chunk and again on the fragment read.
+//  * The K-steps of all tiles of a workgroup form ONE stream: K-step s+2 is requested in the middle of step s, also across
+//    a tile boundary, so a tile's first operands are already in LDS when its first MFMA issues and the previous tile's
+//    output stores drain in the background (no prologue, no store tail between tiles).
+//  * Fragments are read from LDS one phase (16 MFMAs) before the MFMAs that use them.
+// Needs K % 64 == 0 and K >= 128 (no zero-fill on this path).
 #define LBM 256
 #define LBN 256
 #define LTILE (256 * GBK)            // elements per operand tile
+#define NTP_DRAIN 16                 // output stores a wave issues per full tile, at least (16 row groups, one each)
+#define NTP_LDS (4 * LTILE * 2 + 8 * 16 * 64 * 4)   // bytes: operand image + 4 KB of epilogue staging per wave
 
-static __device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* ldst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+// 16 bytes per lane, global -> LDS: lane i's data (read at base + voff) lands at LDS byte m0 + 16*i.  Issued as inline
+// assembly on purpose: when hipcc sees the LDS-DMA builtin in a loop it stops counting LDS reads and waits for ALL of them
+// (lgkmcnt(0)) in front of every MFMA group, which serialises fragment reads and MFMAs; hidden from it, the reads get
+// counted waits.  Completion is tracked by hand (s_waitcnt vmcnt before the publishing barrier).
+static __device__ __forceinline__ void glds16(const bf16_t* base, unsigned voff, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_byte) : "memory", "m0");
+}
+static __device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) void*)p;
 }
 
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmNTParams p) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t lsm[];   // [2 buffers][A tile | B tile]
+__global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t lsm[];   // [2 buffers][A tile | B tile], [8 waves][16][64] fp32
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int lr = lane & 15, lg = lane >> 4;
+    float* stg = reinterpret_cast<float*>(lsm + 4 * LTILE) + wave * (16 * 64);
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lsm));
 
-    const int tile = xcd_remap(blockIdx.x, p.num_tiles);
-    const int m0 = (tile / p.tiles_n) * LBM;
-    const int n0 = (tile % p.tiles_n) * LBN;
-
-    // staging: wave w, instruction j covers rows (w*4+j)*8 .. +7 of the tile; lane -> row += lane/8, position lane%8,
-    // which receives source chunk (lane%8) ^ (row&7)
-    const int srow = lane >> 3, spos = lane & 7;
-    const bf16_t* gA[4];
-    const bf16_t* gB[4];
+    // staging: wave w, piece j covers rows (w*4+j)*8 .. +7 of a tile; lane -> row += lane/8, LDS position lane%8, which
+    // receives source chunk (lane%8) ^ (row&7); row&7 == lane/8 for every piece
+    const int srow = lane >> 3, sch = (lane & 7) ^ srow;
+    const unsigned lds_stage = (unsigned)(wave * 4 * 8 * GBK * sizeof(bf16_t));
+    const bf16_t* sA = p.A;          // staging state: operand panels of the tile being requested
+    const bf16_t* sB = p.B;
+    unsigned voA[4], voB[4];
+    auto aim = [&](int v, int& m0, int& n0) {
+        const int tile = xcd_remap(v, p.num_tiles);
+        const int tm_ = tile / p.tiles_n;
+        m0 = tm_ * LBM;
+        n0 = (tile - tm_ * p.tiles_n) * LBN;
+        sA = p.A + (size_t)m0 * p.lda;
+        sB = p.B + (size_t)n0 * p.ldb;
+        const int ra_max = p.M - 1 - m0, rb_max = p.N - 1 - n0;       // rows past the edge re-read the last valid row
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (wave * 4 + j) * 8 + srow;
-        int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
-        int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
-        const int ch = spos ^ (row & 7);
-        gA[j] = p.A + (size_t)gm * p.lda + ch * 8;
-        gB[j] = p.B + (size_t)gn * p.ldb + ch * 8;
-    }
-    const int lds_stage = wave * 4 * 8 * GBK;     // element offset of this wave's first 8-row group inside a tile
-
-    f32x4 acc[8][4];
+        for (int j = 0; j < 4; ++j) {
+            const int row = (wave * 4 + j) * 8 + srow;
+            const int ra = row < ra_max ? row : ra_max, rb = row < rb_max ? row : rb_max;
+            voA[j] = (unsigned)((ra * p.lda + sch * 8) * (int)sizeof(bf16_t));
+            voB[j] = (unsigned)((rb * p.ldb + sch * 8) * (int)sizeof(bf16_t));
+        }
+    };
+    auto stage = [&](int kstep, int par) {       // K-step kstep of the staging tile -> LDS buffer par (asynchronous)
+        const unsigned dA = lds_base + (unsigned)(par * 2 * LTILE * sizeof(bf16_t)) + lds_stage;
+        const unsigned dB = dA + (unsigned)(LTILE * sizeof(bf16_t));
+        const bf16_t* a = sA + kstep * GBK;
+        const bf16_t* b = sB + kstep * GBK;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) {
+            glds16(a, voA[j], dA + j * 8 * GBK * (unsigned)sizeof(bf16_t));
+            glds16(b, voB[j], dB + j * 8 * GBK * (unsigned)sizeof(bf16_t));
+        }
+    };
 
     // fragment read offsets (elements) inside a tile: row*64 + ((chunk ^ (row&7)) << 3); row&7 == lr&7 for every tile row
     int offA[2], offB[2];
@@ -267,72 +335,159 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const GemmNTParams p) {
         offA[ks] = (wm * 128 + lr) * GBK + x;
         offB[ks] = (wn * 64 + lr) * GBK + x;
     }
+    f32x4 acc[8][4];
+    bf16x8 faE[4], faO[4], fbE[4], fbO[4];
+    auto ldA = [&](bf16x8 (&f)[4], const bf16_t* cA, int ks, int h) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const bf16x8*>(cA + offA[ks] + (4 * h + t) * 16 * GBK);
+    };
+    auto ldB = [&](bf16x8 (&f)[4], const bf16_t* cB, int ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const bf16x8*>(cB + offB[ks] + t * 16 * GBK);
+    };
+    auto mma = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4], int h) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                acc[4 * h + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[4 * h + tm][tn], 0, 0, 0);
+    };
 
     const int nk = p.K / GBK;
-    {
-        bf16_t* dA = lsm + lds_stage;
-        bf16_t* dB = lsm + LTILE + lds_stage;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(gA[j], dA + j * 8 * GBK);
-            glds16(gB[j], dB + j * 8 * GBK);
-        }
-    }
+    const int G = gridDim.x;
+    int v = blockIdx.x;
+    int m0, n0, nm0 = 0, nn0 = 0;
+    aim(v, m0, n0);
+    stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage(1, 1);
+    ldB(fbE, lsm + LTILE, 0);
+    ldA(faE, lsm, 0, 0);
+    int par = 0;            // LDS buffer of the current K-step
+    bool loose = false;     // the last VMEM operations of this wave are >= NTP_DRAIN output stores younger than every request
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const bf16_t* cA = lsm + (kt & 1) * 2 * LTILE;
-        const bf16_t* cB = cA + LTILE;
-        if (kt + 1 < nk) {
-            bf16_t* dA = lsm + ((kt + 1) & 1) * 2 * LTILE + lds_stage;
-            bf16_t* dB = dA + LTILE;
-            const int kofs = (kt + 1) * GBK;
+    for (;;) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                glds16(gA[j] + kofs, dA + j * 8 * GBK);
-                glds16(gB[j] + kofs, dB + j * 8 * GBK);
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool has_next = v + G < p.num_tiles;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const bf16_t* cA = lsm + par * 2 * LTILE;
+            const bf16_t* cB = cA + LTILE;
+            const bf16_t* nA = lsm + (par ^ 1) * 2 * LTILE;
+            const bf16_t* nB = nA + LTILE;
+            // Each phase: 16 MFMAs on fragments fetched a phase ago, interleaved (MFMAs first) with the reads for the next
+            // phase, N-side fragments first because the next phase's first four MFMAs need all of them.
+            // phase (0,0): fetch A rows 64..127 of ks 0
+            mma(faE, fbE, 0);
+            ldA(faO, cA, 0, 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase (0,1): fetch ks 1's N side and A rows 0..63
+            mma(faO, fbE, 1);
+            ldB(fbO, cB, 1);
+            ldA(faE, cA, 1, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase (1,0)
+            mma(faE, fbO, 0);
+            ldA(faO, cA, 1, 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            // Every wave has now read all of the current buffer; the next K-step, requested a full step ago, must have
+            // landed: publish it, then refill the current buffer with the K-step after that.  vmcnt counts in issue order,
+            // so in a tile's first step the previous tile's output stores (all younger than the request) may stay pending.
+            if (kt == 0 && loose) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTP_DRAIN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) {
+                stage(kt + 2, par);
+            } else if (has_next) {
+                if (kt + 2 == nk) aim(v + G, nm0, nn0);
+                stage(kt + 2 - nk, par);
+            }
+            // phase (1,1): fetch the first fragments of the next K-step (after the last tile: stale LDS, never used)
+            mma(faO, fbO, 1);
+            ldB(fbE, nB, 0);
+            ldA(faE, nA, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            par ^= 1;
+        }
+
+        // Epilogue.  The MFMA layout (lane = row lr, 4 columns) would store 32-byte pieces of 16 rows per instruction, and
+        // the store path is paid per lane-access, not per byte.  Transpose through this wave's private 4 KB of LDS instead
+        // (fp32, so the arithmetic is unchanged): 16 rows x 64 columns at a time, read back as lane = (row lane/8, 8
+        // columns), so every global access is 16 bytes per lane and 8 lanes cover one full 128-byte line.
+        // 16-byte chunk c of staging row r sits at chunk c ^ (r & 7): conflict-free both ways.
+        // The side operand (residual / pre-activation) may be the output buffer itself, so hipcc keeps every load behind
+        // the previous store: fetch it by hand, 8 pieces (64 rows) ahead, to keep HBM latency out of the store loop.
+        constexpr bool SIDE = EPI == VITK_EPI_BIAS_RES || EPI == VITK_EPI_DGELU;
+        const int ecol = n0 + wn * 64 + (lane & 7) * 8;
+        u32x4 side[SIDE ? 8 : 1];
+        auto fetch_side = [&](int tm_base) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int m = m0 + wm * 128 + (tm_base + (i >> 1)) * 16 + (i & 1) * 8 + srow;
+                m = m < p.M ? m : p.M - 1;
+                const int n = ecol < p.N ? ecol : 0;
+                side[SIDE ? i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(nt_side_ptr<EPI>(p, m, n)));
+            }
+        };
+        if (SIDE) fetch_side(0);
+        // the bias depends on the lane's columns only: one fetch per tile (behind the stores hipcc would re-load it 16 times)
+        constexpr bool BIAS = EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU;
+        float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (BIAS) add_f32<8>(p.bias + (ecol < p.N ? ecol : 0), bias8);
+#pragma unroll
+        for (int tm = 0; tm < 8; ++tm) {
+            float sv[2][8];
+            if (SIDE) {
+                unpack_bf16x8(side[(tm & 3) * 2], sv[0]);
+                unpack_bf16x8(side[(tm & 3) * 2 + 1], sv[1]);
+                if (tm == 3) { asm volatile("" ::: "memory"); fetch_side(4); }
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                *reinterpret_cast<f32x4*>(stg + lr * 64 + (((tn * 4 + lg) ^ (lr & 7)) << 2)) = acc[tm][tn];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int r = half * 8 + srow;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * 64 + (((2 * (lane & 7)) ^ srow) << 2));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * 64 + (((2 * (lane & 7) + 1) ^ srow) << 2));
+                const int m = m0 + wm * 128 + tm * 16 + r;
+                const int n = ecol;
+                if (m < p.M && n < p.N) {
+                    float rs = 1.0f;
+                    int orow = m;
+                    const float* posrow = nullptr;
+                    if (EPI == VITK_EPI_BIAS_RES) {
+                        if (p.rowscale != nullptr) rs = p.rowscale[m / p.rows_per_group];
+                    }
+                    if (EPI == VITK_EPI_PATCH) {
+                        const int b = m / p.patches, pi = m - b * p.patches;
+                        orow = b * (p.patches + p.prefix) + p.prefix + pi;
+                        posrow = p.pos + (size_t)(p.prefix + pi) * p.N;
+                    }
+                    float o[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    nt_epilogue<EPI, 8>(p, o, m, n, orow, rs, posrow, SIDE ? sv[half] : nullptr, BIAS ? bias8 : nullptr);
+                }
             }
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[8], fb[4];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) fa[t] = *reinterpret_cast<const bf16x8*>(cA + offA[ks] + t * 16 * GBK);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fb[t] = *reinterpret_cast<const bf16x8*>(cB + offB[ks] + t * 16 * GBK);
-#pragma unroll
-            for (int tm = 0; tm < 8; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[tm][tn], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int tm = 0; tm < 8; ++tm) {
-        const int m = m0 + wm * 128 + tm * 16 + lr;
-        if (m >= p.M) continue;
-        float rs = 1.0f;
-        int orow = m;
-        const float* posrow = nullptr;
-        if (EPI == VITK_EPI_BIAS_RES) {
-            if (p.rowscale != nullptr) rs = p.rowscale[m / p.rows_per_group];
-        }
-        if (EPI == VITK_EPI_PATCH) {
-            const int b = m / p.patches, pi = m - b * p.patches;
-            orow = b * (p.patches + p.prefix) + p.prefix + pi;
-            posrow = p.pos + (size_t)(p.prefix + pi) * p.N;
-        }
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int n = n0 + wn * 64 + tn * 16 + 4 * lg;
-            if (n >= p.N) continue;
-            float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-            nt_epilogue<EPI>(p, v, m, n, orow, rs, posrow);
-        }
+        if (!has_next) break;
+        loose = m0 + LBM <= p.M && n0 + LBN <= p.N;      // a full tile: every lane stored all 16 pieces
+        v += G;
+        m0 = nm0;
+        n0 = nn0;
     }
 }
 
@@ -533,6 +688,20 @@ static int tn_splits(int M, int N, int K) {
     return 8 * spx;
 }
 
+// compute units of the current device (cached per device id); <= 0 on failure
+static int vitk_num_cus() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return -1;
+        cache[dev] = n & ~7;      // a multiple of 8 keeps a workgroup's tiles on one XCD's share of the tile order
+        if (cache[dev] == 0) cache[dev] = n;
+    }
+    return cache[dev];
+}
+
 extern "C" {
 
 int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
@@ -565,24 +734,28 @@ int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ld
     p.rowscale = rowscale; p.rows_per_group = rows_per_group; p.out2 = (bf16_t*)out2; p.ldout2 = ldout2;
     p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pos = pos; p.patches = patches; p.prefix = prefix;
     hipStream_t s = (hipStream_t)stream;
-    // large problems with K a multiple of 64 take the 256x256 direct-to-LDS kernel; the 128x128 register-staged kernel
+    // large problems with K a multiple of 64 take the persistent 256x256 direct-to-LDS kernel; the 128x128 register-staged kernel
     // handles K tails (zero fill) and small shapes.  VITK_GEMM_SMALL=1 forces the latter (A/B testing).
     static const bool force_small = getenv("VITK_GEMM_SMALL") != nullptr;
-    const bool big = !force_small && K % GBK == 0 && M >= 512 && N >= 128;
+    const bool ld8 = ldc % 8 == 0 && (!res || ldres % 8 == 0) && (!out2 || ldout2 % 8 == 0) && (!aux || ldaux % 8 == 0);   // 16-byte row pieces
+    const bool big = !force_small && K % GBK == 0 && K >= 2 * GBK && M >= 512 && N >= 128 && N % 8 == 0 && ld8;
     const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_NT);
     if (big) {
         p.tiles_n = (N + LBN - 1) / LBN;
         p.num_tiles = ((M + LBM - 1) / LBM) * p.tiles_n;
-        const size_t smem = (size_t)4 * LTILE * sizeof(bf16_t);
+        const size_t smem = NTP_LDS;
+        const int cus = vitk_num_cus();
+        if (cus <= 0) { vitk_set_error("gemm_nt: cannot query the compute-unit count"); return VITK_ELAUNCH; }
+        const int grid = p.num_tiles < cus ? p.num_tiles : cus;      // one persistent workgroup per CU
 #define VITK_LAUNCH_BIG(E)                                                                                              \
     case E: {                                                                                                           \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             if (e != hipSuccess) { vitk_set_error("gemm_nt: cannot set LDS size: %s", hipGetErrorString(e)); return VITK_ELAUNCH; }    \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        gemm_nt256_kernel<E><<<p.num_tiles, 512, smem, s>>>(p);                                                         \
+        gemm_ntp_kernel<E><<<grid, 512, smem, s>>>(p);                                                         \
     } break;
         switch (epilogue) {
             VITK_LAUNCH_BIG(VITK_EPI_PLAIN)

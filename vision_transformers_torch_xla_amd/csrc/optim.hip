@@ -108,13 +108,13 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, 
 
 extern "C" {
 
-int vitk_ema_update(float* ema, const float* p, float decay, int64_t n, void* stream) {
+int vitk_ema_update(float* ema, const float* p, double decay, int64_t n, void* stream) {
     VITK_REQUIRE(ema && p && n > 0, "ema_update: bad arguments");
     VITK_REQUIRE(vitk_aligned(ema, 16) && vitk_aligned(p, 16), "ema_update: pointers must be 16-byte aligned");
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    ema_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(ema, p, decay, (float)(1.0 - (double)decay), n);
+    ema_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(ema, p, (float)decay, (float)(1.0 - decay), n);
     return vitk_check_launch("ema_update");
 }
 
@@ -125,27 +125,27 @@ int vitk_clip_grad_scale(float* g, int64_t n, const float* sumsq, float max_norm
 }
 
 
-int vitk_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, float* ema, float ema_decay, int64_t n,
-                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+int vitk_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, float* ema, double ema_decay, int64_t n,
+                    double lr, double beta1, double beta2, double eps, double weight_decay, int step, float grad_scale,
                     void* stream) {
     VITK_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad arguments (n=%lld step=%d)", (long long)n, step);
     VITK_REQUIRE(vitk_aligned(p, 16) && vitk_aligned(g, 16) && vitk_aligned(m, 16) && vitk_aligned(v, 16) &&
                      (!p_bf16 || vitk_aligned(p_bf16, 8)) && (!ema || vitk_aligned(ema, 16)),
                  "adamw_step: pointers must be 16-byte aligned (bf16 copy: 8)");
     // host-side scalars in double, as torch's single-tensor path computes them in Python floats
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
+    // (hyper-parameters arrive as doubles for that reason: 1 - 0.999f is off by 1.3e-5 relative from 1 - 0.999)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    const float decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
-    // 1-beta in double first: 1.0f - 0.999f is off by 1.3e-5 relative from the Python float torch uses
-    const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
-    const float omd = (float)(1.0 - (double)ema_decay);
+    const float decay_mul = (float)(1.0 - lr * weight_decay);
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    const float omd = (float)(1.0 - ema_decay);
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    adamw_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, ema, ema_decay, omd, n, beta2, omb1, omb2,
-                                                              eps, decay_mul, step_size, inv_bc2_sqrt, grad_scale);
+    adamw_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, ema, (float)ema_decay, omd, n, (float)beta2, omb1, omb2,
+                                                              (float)eps, decay_mul, step_size, inv_bc2_sqrt, grad_scale);
     return vitk_check_launch("adamw_step");
 }
 
