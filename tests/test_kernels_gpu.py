@@ -145,8 +145,12 @@ def test_gemm_nt_patch_epilogue(device):
     assert torch.count_nonzero(got[:, :pre]) == 0    # prefix rows untouched
 
 
+# the last four take the large-tile path (M >= 8192, N, K >= 256): full tiles, ragged M (not a multiple of 64), ragged
+# N / K (not multiples of 256), and a single row range per tile
 @pytest.mark.parametrize("M,N,K,bias", [(1000, 192, 768, True), (4096, 768, 768, True), (130, 1000, 768, False),
-                                        (197 * 8, 2304, 768, True), (64, 8, 8, True), (513, 3072, 768, False)])
+                                        (197 * 8, 2304, 768, True), (64, 8, 8, True), (513, 3072, 768, False),
+                                        (8192, 768, 768, True), (197 * 48 + 5, 1000, 328, True), (197 * 64, 2304, 768, False),
+                                        (8200, 4096, 3072, True)])
 def test_gemm_tn(device, M, N, K, bias):
     ops = _ops()
     g = torch.Generator().manual_seed(M + 3 * N + K)

@@ -688,6 +688,229 @@ static int tn_splits(int M, int N, int K) {
     return 8 * spx;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// gemm_tn, large-tile variant for the weight gradients of the big linears.  The contraction runs over the M token rows, which
+// are the slow dimension of both operands, so there is plenty of M to split: the work is T output tiles (256 x 256) times R
+// row ranges with T * R just under the CU count, ONE task per workgroup and no second round (no tail), each task one long
+// pipelined loop of 64-row steps.  Tasks are numbered range-major and an XCD takes a contiguous block of them, so the
+// workgroups that share an L2 read (almost) the same rows.  Partial tiles go to fp32 slabs [task][256][256], summed in a
+// fixed order by reduce_tiles_kernel.
+//  * 8 waves (2 x 4), each 128 (n) x 64 (k) = 8 x 4 MFMA tiles; operands global -> LDS by DMA into a double-buffered
+//    128 KB image [m][256 columns]; fragments come from the transposing read (ds_read_b64_tr_b16), one phase ahead.
+//  * rows past M (last step of the last range) are fetched from a zero row, so they add nothing.
+//  * the bias gradient (column sums of A) rides along as MFMAs against an all-ones fragment in the k-tile-0 tasks.
+struct GemmTNBigParams {
+    const bf16_t* A; int lda;
+    const bf16_t* B; int ldb;
+    float* slab;        // [R * T][256][256]
+    float* colslab;     // [R][N] or null
+    int M, N, K;
+    int T, tiles_k, R, steps_total, ntasks;
+};
+
+__device__ __attribute__((aligned(512))) unsigned vitk_zero_row[128];     // 512 bytes of zeros (never written)
+
+static __device__ __forceinline__ void glds16_v(const void* src, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte) : "memory", "m0");
+}
+
+#define TNB_TILE (64 * 256)      // elements per operand tile: 64 rows x 256 columns
+
+template <bool COLSUM>
+__global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t lsm[];   // [2 buffers][A tile | B tile]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int lq = lr >> 2, lp = lr & 3;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lsm));
+
+    const int task = xcd_remap(blockIdx.x, p.ntasks);
+    const int range = task / p.T, tile = task - range * p.T;
+    const int tn_ = tile / p.tiles_k;
+    const int n0 = tn_ * 256, k0 = (tile - tn_ * p.tiles_k) * 256;
+    const int step0 = (int)(((long long)range * p.steps_total) / p.R);
+    const int nsteps = (int)(((long long)(range + 1) * p.steps_total) / p.R) - step0;      // >= 2 (host)
+    const bool do_colsum = COLSUM && k0 == 0;
+
+    // staging: a piece (one wave-instruction, 1 KB) is 2 rows x 512 B; wave w, piece j -> local rows (4w+j)*2 + lane/32;
+    // LDS position lane%32 of row m receives source chunk (lane%32) ^ tn_swz(m)
+    const int shalf = lane >> 5, spos = lane & 31;
+    unsigned voA[4], voB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lrow = (wave * 4 + j) * 2 + shalf;
+        const int ch = spos ^ tn_swz(lrow);
+        int ca = n0 + ch * 8; ca = ca < p.N ? ca : p.N - 8;         // columns past the edge only feed outputs nobody reads
+        int cb = k0 + ch * 8; cb = cb < p.K ? cb : p.K - 8;
+        voA[j] = (unsigned)((lrow * p.lda + ca) * (int)sizeof(bf16_t));
+        voB[j] = (unsigned)((lrow * p.ldb + cb) * (int)sizeof(bf16_t));
+    }
+    const unsigned lds_stage = (unsigned)(wave * 4 * 1024);
+    auto stage = [&](int st, int par) {       // 64-row step st of this range -> LDS buffer par (asynchronous)
+        const unsigned dA = lds_base + (unsigned)(par * 2 * TNB_TILE * sizeof(bf16_t)) + lds_stage;
+        const unsigned dB = dA + (unsigned)(TNB_TILE * sizeof(bf16_t));
+        const int mrow = (step0 + st) * 64;
+        const bf16_t* a = p.A + (size_t)mrow * p.lda;
+        const bf16_t* b = p.B + (size_t)mrow * p.ldb;
+        if (mrow + 64 <= p.M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                glds16(a, voA[j], dA + j * 1024);
+                glds16(b, voB[j], dB + j * 1024);
+            }
+        } else {       // ragged last step: rows >= M come from the zero row
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = mrow + (wave * 4 + j) * 2 + shalf < p.M;
+                const void* z = (const char*)vitk_zero_row + spos * 16;
+                glds16_v(ok ? (const void*)((const char*)a + voA[j]) : z, dA + j * 1024);
+                glds16_v(ok ? (const void*)((const char*)b + voB[j]) : z, dB + j * 1024);
+            }
+        }
+    };
+
+    // fragment addresses: rows r0 = ks*32 + 8*lg + lq (and +4), tn_swz(r0) is the same for both ks; the lane's 4 columns of
+    // MFMA tile t are half (lp&1) of chunk (tile base chunk | lp>>1), XOR-swizzled
+    const int sw = tn_swz(8 * lg + lq);
+    const int preA = ((wm * 16) | (lp >> 1)) ^ sw, preB = ((wn * 8) | (lp >> 1)) ^ sw;
+    const int rbase = (8 * lg + lq) * 256 + (lp & 1) * 4;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 cs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    bf16x8 faE[4], faO[4], fbE[4], fbO[4];
+    auto ldA = [&](bf16x8 (&f)[4], const bf16_t* cA, int ks, int h) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16_t* q = cA + ks * 32 * 256 + rbase + ((preA ^ (2 * (4 * h + t))) << 3);
+            f[t] = tr_frag(q, q + 4 * 256);
+        }
+    };
+    auto ldB = [&](bf16x8 (&f)[4], const bf16_t* cB, int ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16_t* q = cB + ks * 32 * 256 + rbase + ((preB ^ (2 * t)) << 3);
+            f[t] = tr_frag(q, q + 4 * 256);
+        }
+    };
+    auto mma = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4], int h) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                acc[4 * h + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[4 * h + tm][tn], 0, 0, 0);
+        // column sums of A: wave (wm, wn) owns row tiles 2*wn and 2*wn+1 of its 128 rows
+        if (do_colsum && h == (wn >> 1)) {
+            if (wn & 1) {
+                cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[2], cs[0], 0, 0, 0);
+                cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[3], cs[1], 0, 0, 0);
+            } else {
+                cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0], cs[0], 0, 0, 0);
+                cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[1], cs[1], 0, 0, 0);
+            }
+        }
+    };
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage(1, 1);
+    ldB(fbE, lsm + TNB_TILE, 0);
+    ldA(faE, lsm, 0, 0);
+
+    for (int st = 0; st < nsteps; ++st) {
+        const int par = st & 1;
+        const bf16_t* cA = lsm + par * 2 * TNB_TILE;
+        const bf16_t* cB = cA + TNB_TILE;
+        const bf16_t* nA = lsm + (par ^ 1) * 2 * TNB_TILE;
+        const bf16_t* nB = nA + TNB_TILE;
+        // same four-phase pipeline as the persistent gemm_nt kernel: 16 MFMAs on fragments fetched a phase ago, interleaved
+        // with the transposing reads for the next phase
+        mma(faE, fbE, 0);
+        ldA(faO, cA, 0, 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(faO, fbE, 1);
+        ldB(fbO, cB, 1);
+        ldA(faE, cA, 1, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(faE, fbO, 0);
+        ldA(faO, cA, 1, 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 2 < nsteps) stage(st + 2, par);
+        mma(faO, fbO, 1);
+        ldB(fbE, nB, 0);
+        ldA(faE, nA, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // partial tile -> slab (streaming): lane = row lr of MFMA tile tm, 4 consecutive k
+    float* slab = p.slab + (size_t)task * (256 * 256);
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+            __builtin_nontemporal_store(acc[tm][tn], reinterpret_cast<f32x4*>(slab + (wm * 128 + tm * 16 + lr) * 256 + wn * 64 + tn * 16 + 4 * lg));
+    if (do_colsum && lg == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = n0 + wm * 128 + (2 * wn + i) * 16 + lr;
+            if (n < p.N) p.colslab[(size_t)range * p.N + n] = cs[i][0];
+        }
+    }
+}
+
+// out[n*ldo + k] = (accumulate ? out : 0) + sum over the R row ranges of the tile slabs, fixed order; K % 4 == 0
+__global__ void reduce_tiles_kernel(const float* __restrict__ slab, int R, int T, int tiles_k, int N, int K, float* __restrict__ out,
+                                    int ldo, int accumulate) {
+    const size_t total4 = (size_t)N * K / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int n = (int)(e / K), k = (int)(e % K);
+        const int tile = (n >> 8) * tiles_k + (k >> 8);
+        const float* src = slab + (size_t)tile * 65536 + (n & 255) * 256 + (k & 255);
+        f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+        for (int r = 1; r < R; ++r) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)r * T * 65536));
+        f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)n * ldo + k);
+        if (accumulate) s += *dst;
+        *dst = s;
+    }
+}
+
+// plan of the large-tile variant: false -> use the 128x128 kernel
+struct TnPlan { bool big; int T, tiles_k, R, steps_total; };
+static TnPlan tn_plan(int M, int N, int K) {
+    TnPlan q = {false, 0, 0, 0, 0};
+    static const bool force_small = getenv("VITK_GEMM_SMALL") != nullptr;
+    if (force_small || M < 8192 || N < 256 || K < 256) return q;
+    q.tiles_k = (K + 255) / 256;
+    q.T = ((N + 255) / 256) * q.tiles_k;
+    q.steps_total = (M + 63) / 64;
+    if (q.T > 256) return q;
+    q.R = 256 / q.T;
+    if (q.R > q.steps_total / 2) q.R = q.steps_total / 2;
+    q.big = q.R >= 1;
+    return q;
+}
+
 // compute units of the current device (cached per device id); <= 0 on failure
 static int vitk_num_cus() {
     static int cache[64] = {0};
@@ -786,6 +1009,8 @@ int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ld
 
 size_t vitk_gemm_tn_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const TnPlan q = tn_plan(M, N, K);
+    if (q.big) return ((size_t)q.R * q.T * 65536 + (size_t)q.R * N) * sizeof(float);
     const int s = tn_splits(M, N, K);
     return (size_t)s * ((size_t)N * K + (size_t)N) * sizeof(float);
 }
@@ -803,6 +1028,41 @@ int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int l
         vitk_set_error("gemm_tn: workspace %zu < %zu", workspace_bytes, vitk_gemm_tn_workspace(M, N, K));
         return VITK_ENOSPC;
     }
+    hipStream_t s = (hipStream_t)stream;
+    const TnPlan q = tn_plan(M, N, K);
+    if (q.big) {
+        GemmTNBigParams b;
+        b.A = (const bf16_t*)A; b.lda = lda; b.B = (const bf16_t*)B; b.ldb = ldb;
+        b.slab = (float*)workspace;
+        b.colslab = dbias ? b.slab + (size_t)q.R * q.T * 65536 : nullptr;
+        b.M = M; b.N = N; b.K = K; b.T = q.T; b.tiles_k = q.tiles_k; b.R = q.R; b.steps_total = q.steps_total;
+        b.ntasks = q.R * q.T;
+        const size_t smem = (size_t)4 * TNB_TILE * sizeof(bf16_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_tnb_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tnb_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) { vitk_set_error("gemm_tn: cannot set LDS size: %s", hipGetErrorString(e)); return VITK_ELAUNCH; }
+            attr_set = true;
+        }
+        const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_TN);
+        if (dbias) gemm_tnb_kernel<true><<<b.ntasks, 512, smem, s>>>(b);
+        else gemm_tnb_kernel<false><<<b.ntasks, 512, smem, s>>>(b);
+        if (pr) vitk_prof_end(stream);
+        int rc = vitk_check_launch("gemm_tn");
+        if (rc) return rc;
+        const size_t total4 = (size_t)N * K / 4;
+        int rgrid = (int)((total4 + 255) / 256);
+        if (rgrid > 2048) rgrid = 2048;
+        reduce_tiles_kernel<<<rgrid, 256, 0, s>>>(b.slab, q.R, q.T, q.tiles_k, N, K, C, ldc, accumulate);
+        rc = vitk_check_launch("gemm_tn_reduce");
+        if (rc) return rc;
+        if (dbias) {
+            reduce_vec_kernel<<<(N + 255) / 256, 256, 0, s>>>(b.colslab, q.R, N, dbias, accumulate);
+            rc = vitk_check_launch("gemm_tn_reduce_bias");
+        }
+        return rc;
+    }
     const int splits = tn_splits(M, N, K);
     GemmTNParams p;
     p.A = (const bf16_t*)A; p.lda = lda; p.B = (const bf16_t*)B; p.ldb = ldb;
@@ -817,7 +1077,6 @@ int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int l
     p.tiles = tiles_n * p.tiles_k;
     p.splits_per_xcd = splits / 8;
     dim3 grid(p.tiles * splits);
-    hipStream_t s = (hipStream_t)stream;
     const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_TN);
     if (dbias) gemm_tn_kernel<true><<<grid, 256, 0, s>>>(p);
     else gemm_tn_kernel<false><<<grid, 256, 0, s>>>(p);
