@@ -19,10 +19,9 @@ static __device__ __forceinline__ bf16x8 tr_frag2(const bf16_t* lo, const bf16_t
     return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 static __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
-    bf16x8 r;
-    r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
-    r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
-    return r;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    const u4 r = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, r);
 }
 // [rows][64] bf16 image with the 16-byte chunk index XOR-swizzled by (row & 7): element offset of (row, col)
 static __device__ __forceinline__ int swz(int row, int col) {

@@ -41,46 +41,70 @@ __global__ void prefix_tokens_kernel(const float* __restrict__ tokens, const flo
     }
 }
 
-// dpos[t][d] = sum_b dx[b][t][d]; one thread per (t, d-pair), loop over b (coalesced across d)
+// dpos[t][:] = sum_b dx[b][t][:].  One block per token t: thread = (8-column vector cv, batch group bg); every group sums
+// its share of the batch with 16-byte loads, the groups are folded through LDS in a fixed order (deterministic).
 __global__ void pos_tokens_bwd_kernel(const bf16_t* __restrict__ dx, float* __restrict__ dpos, float* __restrict__ dtok,
-                                      int accumulate, int B, int N, int D, int prefix) {
-    const size_t total = (size_t)N * (D / 2);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i % (D / 2)) * 2;
-        const int t = (int)(i / (D / 2));
-        float s0 = 0.f, s1 = 0.f;
-        for (int b = 0; b < B; ++b) {
-            const unsigned w = *reinterpret_cast<const unsigned*>(dx + ((size_t)b * N + t) * D + d);
-            s0 += __uint_as_float(w << 16);
-            s1 += __uint_as_float(w & 0xffff0000u);
-        }
-        float* pp = dpos + (size_t)t * D + d;
-        if (accumulate) { pp[0] += s0; pp[1] += s1; } else { pp[0] = s0; pp[1] = s1; }
-        if (t < prefix && dtok != nullptr) {
-            float* tp = dtok + (size_t)t * D + d;
-            if (accumulate) { tp[0] += s0; tp[1] += s1; } else { tp[0] = s0; tp[1] = s1; }
-        }
-    }
-}
-
-// y[b][d] = mean_{t>=first} x[b][t][d]; thread per (b, 8 columns)
-__global__ void pool_avg_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int N, int D, int first) {
+                                      int accumulate, int B, int N, int D, int prefix, int groups) {
+    extern __shared__ float ptb_smem[];     // [groups][D]
     const int nv = D / 8;
-    const size_t total = (size_t)B * nv;
-    const float inv = 1.0f / (float)(N - first);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % nv) * 8;
-        const int b = (int)(i / nv);
-        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int t = first; t < N; ++t) {
+    const int t = blockIdx.x;
+    const int cv = threadIdx.x % nv, bg = threadIdx.x / nv;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (bg < groups) {
+        for (int b = bg; b < B; b += groups) {
             float v[8];
-            load8(x + ((size_t)b * N + t) * D + c, v);
+            load8(dx + ((size_t)b * N + t) * D + cv * 8, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] += v[j];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] *= inv;
-        store8(y + (size_t)b * D + c, s);
+        for (int j = 0; j < 8; ++j) ptb_smem[bg * D + cv * 8 + j] = s[j];
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float r = 0.f;
+        for (int k = 0; k < groups; ++k) r += ptb_smem[k * D + d];
+        float* pp = dpos + (size_t)t * D + d;
+        *pp = accumulate ? *pp + r : r;
+        if (t < prefix && dtok != nullptr) {
+            float* tp = dtok + (size_t)t * D + d;
+            *tp = accumulate ? *tp + r : r;
+        }
+    }
+}
+
+// y[b][:] = mean_{t>=first} x[b][t][:].  Block = (sample b, 32 column vectors); thread = (vector, one of 8 token groups);
+// the token groups are folded through LDS in a fixed order.
+__global__ __launch_bounds__(256) void pool_avg_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int N, int D,
+                                                            int first) {
+    __shared__ float part[8][32 * 8 + 4];
+    const int nv = D / 8;
+    const int cgroups = (nv + 31) / 32;
+    const int b = blockIdx.x / cgroups, cg = blockIdx.x % cgroups;
+    const int cv = cg * 32 + (threadIdx.x & 31), tg = threadIdx.x >> 5;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cv < nv) {
+        for (int t = first + tg; t < N; t += 8) {
+            float v[8];
+            load8(x + ((size_t)b * N + t) * D + cv * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[tg][(threadIdx.x & 31) * 8 + j] = s[j];
+    __syncthreads();
+    if (tg == 0 && cv < nv) {
+        const float inv = 1.0f / (float)(N - first);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r += part[k][(threadIdx.x & 31) * 8 + j];
+            o[j] = r * inv;
+        }
+        store8(y + (size_t)b * D + cv * 8, o);
     }
 }
 
@@ -225,8 +249,15 @@ int vitk_prefix_tokens_fwd(const float* tokens, const float* pos, void* x, int B
 
 int vitk_pos_tokens_bwd(const void* dx, float* dpos, float* dtokens, int accumulate, int B, int N, int D, int prefix, void* stream) {
     VITK_REQUIRE(dx && dpos, "pos_tokens_bwd: null pointer");
-    VITK_REQUIRE(B > 0 && N > 0 && D > 0 && D % 2 == 0 && prefix >= 0 && prefix <= N, "pos_tokens_bwd: bad shape");
-    pos_tokens_bwd_kernel<<<ew_grid((size_t)N * D / 2), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)dx, dpos, dtokens, accumulate, B, N, D, prefix);
+    VITK_REQUIRE(B > 0 && N > 0 && D > 0 && D % 8 == 0 && D <= 8192 && prefix >= 0 && prefix <= N, "pos_tokens_bwd: bad shape (D %% 8 == 0, D <= 8192)");
+    VITK_REQUIRE(vitk_aligned(dx, 16), "pos_tokens_bwd: dx must be 16-byte aligned");
+    const int nv = D / 8;
+    int groups = 1024 / nv;
+    if (groups > 12) groups = 12;          // groups * D * 4 bytes of LDS <= 48 KB at D = 1024
+    if (groups > B) groups = B;
+    if (groups < 1) groups = 1;
+    pos_tokens_bwd_kernel<<<N, nv * groups, (size_t)groups * D * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)dx, dpos, dtokens, accumulate, B, N, D,
+                                                                                                   prefix, groups);
     return vitk_check_launch("pos_tokens_bwd");
 }
 
@@ -234,7 +265,7 @@ int vitk_pool_avg_fwd(const void* x, void* y, int B, int N, int D, int first, vo
     VITK_REQUIRE(x && y, "pool_avg_fwd: null pointer");
     VITK_REQUIRE(B > 0 && N > first && first >= 0 && D % 8 == 0, "pool_avg_fwd: bad shape");
     VITK_REQUIRE(vitk_aligned(x, 16) && vitk_aligned(y, 16), "pool_avg_fwd: pointers must be 16-byte aligned");
-    pool_avg_fwd_kernel<<<ew_grid((size_t)B * D / 8), 64, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, B, N, D, first);
+    pool_avg_fwd_kernel<<<B * ((D / 8 + 31) / 32), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)y, B, N, D, first);
     return vitk_check_launch("pool_avg_fwd");
 }
 

@@ -116,10 +116,23 @@ static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float 
         for (int i = 0; i < W; i += 4)
             *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
     } else if (EPI == VITK_EPI_BIAS_GELU) {
+        // round the pre-activation to bf16 once (the stored value), apply GELU to exactly that value
+        unsigned hp[W / 2];
         float a[W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) a[j] = gelu_erf(bf2f(f2bf(v[j])));
-        store_bf16<W>((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+        for (int j = 0; j < W; j += 2) {
+            hp[j / 2] = pack2bf(v[j], v[j + 1]);
+            a[j] = gelu_erf(__uint_as_float(hp[j / 2] << 16));
+            a[j + 1] = gelu_erf(__uint_as_float(hp[j / 2] & 0xffff0000u));
+        }
+        bf16_t* cp = (bf16_t*)p.C + (size_t)m * p.ldc + n;
+        if (W == 4) {
+            uint2 r; r.x = hp[0]; r.y = hp[1];
+            *reinterpret_cast<uint2*>(cp) = r;
+        } else {
+            const u32x4 r = {hp[0], hp[1], hp[W / 2 - 2], hp[W / 2 - 1]};
+            __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(cp));
+        }
         store_bf16<W>(p.out2 + (size_t)m * p.ldout2 + n, a);
     } else if (EPI == VITK_EPI_BIAS_RES) {
         float r[W];

@@ -147,21 +147,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nrows, int D, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int accumulate) {
-    // block = 32 columns x 8 row groups; fixed summation order => bitwise reproducible
-    __shared__ float red[8][33];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nrows, int D,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    // block = 16 columns x 64 row groups; fixed summation order => bitwise reproducible
+    __shared__ float red[64][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     float s = 0.f;
     if (c < 2 * D)
-        for (int r = ry; r < nrows; r += 8) s += partial[(size_t)r * 2 * D + c];
+        for (int r = ry; r < nrows; r += 64) s += partial[(size_t)r * 2 * D + c];
     red[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && c < 2 * D) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][cx];
+        for (int k = 0; k < 64; ++k) t += red[k][cx];
         float* dst = (c < D) ? (dgamma + c) : (dbeta + (c - D));
         *dst = accumulate ? (*dst + t) : t;
     }
@@ -221,7 +221,7 @@ int vitk_layernorm_bwd(const void* dy, const void* x, const float* mean, const f
                                                   (const bf16_t*)dres, (bf16_t*)dx, partial, M, D);
     int rc = vitk_check_launch("layernorm_bwd");
     if (rc) return rc;
-    ln_bwd_reduce_kernel<<<(2 * D + 31) / 32, 256, 0, s>>>(partial, grid, D, dgamma, dbeta, accumulate);
+    ln_bwd_reduce_kernel<<<(2 * D + 15) / 16, 1024, 0, s>>>(partial, grid, D, dgamma, dbeta, accumulate);
     return vitk_check_launch("layernorm_bwd_reduce");
 }
 
