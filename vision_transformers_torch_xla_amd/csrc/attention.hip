@@ -29,87 +29,100 @@ static __device__ __forceinline__ int swz(int row, int col) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// MAXT = number of 16-key tiles held in registers (even).  LDS: Ks [npad][64] swizzled, Vs [npad][64] linear.
-template <int MAXT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                        float* __restrict__ lse, int N, int H, float scale) {
+// One workgroup per (batch, head).  K and V go global -> LDS by DMA (no staging registers), both as [key][64] with the
+// 16-byte chunk XOR-swizzled by (key & 7): conflict-free for the ds_read_b128 fragments of K and for the transposing reads of
+// V alike.  Rows past N repeat row N-1 (finite data): their scores are forced to -inf and 0 * finite = 0 in P V.
+// MAXT = 2 * ceil(N / 32) key tiles of 16, all held in registers, is a template parameter, so the loops carry no run-time
+// bounds: tiles below MAXT-2 are entirely real keys; the last two start their score accumulators at -inf where the key is
+// padding (C = -inf + finite stays -inf), which is the whole masking cost.
+// WAVES waves per workgroup and WPE waves per SIMD asked of the compiler: 7 and 4 up to 224 keys (13 query tiles at 197
+// tokens = at most 2 per wave; two workgroups per CU), 4 and 1 beyond.
+template <int MAXT, int WAVES, int WPE>
+__global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                   float* __restrict__ lse, int N, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
-    const int npad = ((N + 31) / 32) * 32;
+    constexpr int NPAD = MAXT * 16;
     bf16_t* Ks = reinterpret_cast<bf16_t*>(attn_smem);
-    bf16_t* Vs = Ks + (size_t)npad * HD;
+    bf16_t* Vs = Ks + NPAD * HD;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4, lq = lr >> 2, lp = lr & 3;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int D = H * HD, ld = 3 * D;
     const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
 
-    for (int ci = tid; ci < npad * 8; ci += 256) {
-        const int key = ci >> 3, ch = ci & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < N) {
-            const bf16_t* rowp = base + (size_t)key * ld + ch * 8;
-            kv = *reinterpret_cast<const uint4*>(rowp + D);
-            vv = *reinterpret_cast<const uint4*>(rowp + 2 * D);
+    {   // DMA fill: a piece = 8 rows x 128 B; pieces [0, NPAD/8) are K, the rest V
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(Ks));
+        const int prow = lane >> 3, ppos = lane & 7;
+        for (int pc = wave; pc < 2 * (NPAD / 8); pc += WAVES) {
+            const int which = pc >= NPAD / 8 ? 1 : 0;
+            const int row = (pc - which * (NPAD / 8)) * 8 + prow;
+            const int srow = row < N ? row : N - 1;
+            const bf16_t* src = base + (size_t)srow * ld + (1 + which) * D + ((ppos ^ (row & 7)) << 3);
+            glds16_v(src, lds0 + (unsigned)pc * 1024u);
         }
-        *reinterpret_cast<uint4*>(&Ks[key * HD + ((ch ^ (key & 7)) << 3)]) = kv;
-        *reinterpret_cast<uint4*>(&Vs[key * HD + ch * 8]) = vv;
     }
+
+    const int nqt = (N + 15) / 16;
+    const float c2 = scale * 1.44269504088896340736f;      // softmax in base 2
+    f32x4 tail0[2];     // accumulator start values of the last two key tiles: 0 for a real key, -inf for padding
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tail0[i][r] = ((MAXT - 2 + i) * 16 + 4 * lg + r < N) ? 0.f : -INFINITY;
+    const int koff0 = lr * HD + ((lg ^ (lr & 7)) << 3), koff1 = lr * HD + (((4 + lg) ^ (lr & 7)) << 3);   // (16t + lr) & 7 == lr & 7
+    int voff[4];        // (32u + 4lg + lq) & 7 == (4lg + lq) & 7, and the same 16 rows further: one offset per d tile serves all u
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) voff[dt] = swz(4 * lg + lq, dt * 16 + 4 * lp);
+
+    auto load_q = [&](int qt, bf16x8 (&qf)[2]) {
+        int q = qt * 16 + lr;
+        q = q < N ? q : N - 1;
+        const bf16_t* qp = base + (size_t)q * ld + 8 * lg;
+        qf[0] = *reinterpret_cast<const bf16x8*>(qp);
+        qf[1] = *reinterpret_cast<const bf16x8*>(qp + 32);
+    };
+    bf16x8 qf[2], qn[2];
+    if (wave < nqt) load_q(wave, qf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int nkt = npad / 16;          // even, <= MAXT
-    const int nqt = (N + 15) / 16;
-    for (int qt = wave; qt < nqt; qt += 4) {
-        int q = qt * 16 + lr;
-        const bool qvalid = q < N;
-        if (!qvalid) q = N - 1;
-        bf16x8 qf[2];
-        {
-            const bf16_t* qp = base + (size_t)q * ld + 8 * lg;
-            qf[0] = *reinterpret_cast<const bf16x8*>(qp);
-            qf[1] = *reinterpret_cast<const bf16x8*>(qp + 32);
-        }
+    for (int qt = wave; qt < nqt; qt += WAVES) {
+        if (qt + WAVES < nqt) load_q(qt + WAVES, qn);      // the next tile's queries travel under this tile's work
+        // K fragments are fetched one key tile ahead by hand and the scheduler is fenced per tile: left alone, hipcc hoists every
+        // fragment load of the unrolled loop to the top and spills
         f32x4 s[MAXT];
+        bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(&Ks[koff0]);
+        bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(&Ks[koff1]);
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (t < nkt) {
-                const int key = t * 16 + lr;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[key * HD + (((ks * 4 + lg) ^ (key & 7)) << 3)]);
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
-                }
+            const bf16x8 a0 = kf0, a1 = kf1;
+            if (t + 1 < MAXT) {
+                kf0 = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HD + koff0]);
+                kf1 = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HD + koff1]);
             }
+            s[t] = t < MAXT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (MAXT - 2)];
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], s[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // s[t][r] = S^T[key = 16t + 4lg + r][q = lr]; scale, mask the padded keys, softmax over keys
-        float mx = -INFINITY;
+        // s[t][r] = S^T[key = 16t + 4lg + r][q = lr] (unscaled)
+        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            if (t < nkt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = t * 16 + 4 * lg + r;
-                    const float v = (key < N) ? s[t][r] * scale : -INFINITY;
-                    s[t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            }
-        }
+        for (int t = 1; t < MAXT; ++t) mx = fmaxf(fmaxf(mx, s[t][0]), fmaxf(fmaxf(s[t][1], s[t][2]), s[t][3]));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmc = -mx * c2;
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            if (t < nkt) {
+        for (int t = 0; t < MAXT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(s[t][r] - mx);
-                    s[t][r] = e;
-                    sum += e;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c2, nmc));
+                s[t][r] = e;
+                sum += e;
             }
-        }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
@@ -119,18 +132,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < MAXT / 2; ++u) {
-            if (2 * u < nkt) {
-                const bf16x8 pb = pack8(s[2 * u], s[2 * u + 1]);
-                const int r0 = 32 * u + 4 * lg + lq;
+            const bf16x8 pb = pack8(s[2 * u], s[2 * u + 1]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8 va = tr_frag2(&Vs[r0 * HD + dt * 16 + 4 * lp], &Vs[(r0 + 16) * HD + dt * 16 + 4 * lp]);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[dt], 0, 0, 0);
-                }
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16_t* vp = Vs + u * 32 * HD + voff[dt];
+                const bf16x8 va = tr_frag2(vp, vp + 16 * HD);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[dt], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // o[dt][r] = O^T[d = 16dt + 4lg + r][q = lr]
-        if (qvalid) {
+        const int q = qt * 16 + lr;
+        if (q < N) {
             bf16_t* op = out + ((size_t)b * N + q) * D + h * HD + 4 * lg;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -139,8 +152,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                 w.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
                 *reinterpret_cast<uint2*>(op + dt * 16) = w;
             }
-            if (lg == 0) lse[((size_t)b * H + h) * N + q] = mx + __logf(sum);
+            if (lg == 0) lse[((size_t)b * H + h) * N + q] = (mx * c2 + __builtin_amdgcn_logf(sum)) * 0.69314718055994530942f;
         }
+        qf[0] = qn[0];
+        qf[1] = qn[1];
     }
 }
 
@@ -383,19 +398,27 @@ int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int
     VITK_REQUIRE(qkv && out && lse, "attention_fwd: null pointer");
     VITK_REQUIRE(B > 0 && N > 0 && H > 0 && N <= 608, "attention_fwd: need B,H>0 and 0<N<=608 (B=%d N=%d H=%d)", B, N, H);
     VITK_REQUIRE(vitk_aligned(qkv, 16) && vitk_aligned(out, 16), "attention_fwd: pointers must be 16-byte aligned");
-    const int npad = ((N + 31) / 32) * 32;
-    const size_t smem = (size_t)2 * npad * HD * sizeof(bf16_t);
+    const int maxt = 2 * ((N + 31) / 32);
+    const size_t smem = (size_t)2 * maxt * 16 * HD * sizeof(bf16_t);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if (npad <= 224) {
-        e = hipFuncSetAttribute((const void*)attn_fwd_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) { vitk_set_error("attention_fwd: cannot set LDS size %zu: %s", smem, hipGetErrorString(e)); return VITK_ELAUNCH; }
-        attn_fwd_kernel<14><<<B * H, 256, smem, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
-    } else {
-        e = hipFuncSetAttribute((const void*)attn_fwd_kernel<38>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) { vitk_set_error("attention_fwd: cannot set LDS size %zu: %s", smem, hipGetErrorString(e)); return VITK_ELAUNCH; }
-        attn_fwd_kernel<38><<<B * H, 256, smem, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+    static bool attr_done[40] = {false};
+#define VITK_FWD_CASE(T, W, E)                                                                                              \
+    case T: {                                                                                                               \
+        if (!attr_done[T]) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, W, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            if (e != hipSuccess) { vitk_set_error("attention_fwd: cannot set LDS size %zu: %s", smem, hipGetErrorString(e)); return VITK_ELAUNCH; } \
+            attr_done[T] = true;                                                                                            \
+        }                                                                                                                   \
+        attn_fwd_kernel<T, W, E><<<B * H, W * 64, smem, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);          \
+    } break;
+    switch (maxt) {
+        VITK_FWD_CASE(2, 4, 4) VITK_FWD_CASE(4, 4, 4) VITK_FWD_CASE(6, 4, 4) VITK_FWD_CASE(8, 4, 4) VITK_FWD_CASE(10, 7, 4)
+        VITK_FWD_CASE(12, 7, 4) VITK_FWD_CASE(14, 7, 4) VITK_FWD_CASE(16, 4, 2) VITK_FWD_CASE(18, 4, 2) VITK_FWD_CASE(20, 4, 2)
+        VITK_FWD_CASE(22, 4, 2) VITK_FWD_CASE(24, 4, 2) VITK_FWD_CASE(26, 4, 1) VITK_FWD_CASE(28, 4, 1) VITK_FWD_CASE(30, 4, 1)
+        VITK_FWD_CASE(32, 4, 1) VITK_FWD_CASE(34, 4, 1) VITK_FWD_CASE(36, 4, 1) VITK_FWD_CASE(38, 4, 1)
+        default: vitk_set_error("attention_fwd: unsupported token count %d", N); return VITK_EINVAL;
     }
+#undef VITK_FWD_CASE
     return vitk_check_launch("attention_fwd");
 }
 

@@ -26,6 +26,21 @@ static __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
+// 16 bytes per lane, global -> LDS: lane i's data (read at base + voff) lands at LDS byte m0 + 16*i.  Issued as inline
+// assembly on purpose: when hipcc sees the LDS-DMA builtin in a loop it stops counting LDS reads and waits for ALL of them
+// (lgkmcnt(0)) in front of every MFMA group, which serialises fragment reads and MFMAs; hidden from it, the reads get
+// counted waits.  Completion is tracked by hand (s_waitcnt vmcnt before the publishing barrier).
+static __device__ __forceinline__ void glds16(const bf16_t* base, unsigned voff, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_byte) : "memory", "m0");
+}
+static __device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) void*)p;
+}
+// the same with a full 64-bit address per lane
+static __device__ __forceinline__ void glds16_v(const void* src, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte) : "memory", "m0");
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

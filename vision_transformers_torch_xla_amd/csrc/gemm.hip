@@ -283,17 +283,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTParams p) {
 #define NTP_DRAIN 16                 // output stores a wave issues per full tile, at least (16 row groups, one each)
 #define NTP_LDS (4 * LTILE * 2 + 8 * 16 * 64 * 4)   // bytes: operand image + 4 KB of epilogue staging per wave
 
-// 16 bytes per lane, global -> LDS: lane i's data (read at base + voff) lands at LDS byte m0 + 16*i.  Issued as inline
-// assembly on purpose: when hipcc sees the LDS-DMA builtin in a loop it stops counting LDS reads and waits for ALL of them
-// (lgkmcnt(0)) in front of every MFMA group, which serialises fragment reads and MFMAs; hidden from it, the reads get
-// counted waits.  Completion is tracked by hand (s_waitcnt vmcnt before the publishing barrier).
-static __device__ __forceinline__ void glds16(const bf16_t* base, unsigned voff, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_byte) : "memory", "m0");
-}
-static __device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) void*)p;
-}
-
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lsm[];   // [2 buffers][A tile | B tile], [8 waves][16][64] fp32
@@ -724,9 +713,6 @@ struct GemmTNBigParams {
 
 __device__ __attribute__((aligned(512))) unsigned vitk_zero_row[128];     // 512 bytes of zeros (never written)
 
-static __device__ __forceinline__ void glds16_v(const void* src, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte) : "memory", "m0");
-}
 
 #define TNB_TILE (64 * 256)      // elements per operand tile: 64 rows x 256 columns
 
