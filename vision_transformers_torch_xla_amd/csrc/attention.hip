@@ -13,6 +13,8 @@
 
 #define HD 64   // head dim
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
 static __device__ __forceinline__ bf16x8 tr_frag2(const bf16_t* lo, const bf16_t* hi) {
     const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)lo);
     const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)hi);
@@ -376,6 +378,252 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------- backward, resident variant
+// For heads of at most 224 tokens everything a head needs fits in LDS at once: Q, K, V, dO as [NPAD][64] images (chunk
+// XOR-swizzled by row & 7, filled by DMA) plus lse and delta = rowsum(dO * O) per query.  The kernel then runs two
+// barrier-free phases and recomputes the scores in the second instead of passing dS between waves:
+//   phase 1, a wave owns key tiles:   S = Q K^T, dP = dO V^T (key on the lane), P = 2^(S c - lse'), dS = P (dP - delta) scale,
+//                                     dV^T += dO^T P, dK^T += Q^T dS   (Q^T, dO^T by transposing reads)
+//   phase 2, a wave owns query tiles: S^T = K Q^T, dP^T = V dO^T (query on the lane), same P and dS, dQ^T += K^T dS^T.
+// Padding: query rows >= N carry lse' = +inf, so P = dS = 0 there; key rows >= N start the S^T accumulators of phase 2 at
+// -inf (tiles below MAXT-2 are all real keys); in phase 1 padded keys only feed dK/dV rows that are never stored.
+// MAXT = 2 * ceil(N / 32) key tiles is a template parameter: no run-time loop bounds.
+template <int MAXT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                     bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+    constexpr int NPAD = MAXT * 16;
+    constexpr int TPW = (MAXT + WAVES - 1) / WAVES;        // key tiles (phase 1) / query tiles (phase 2) per wave
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(attn_smem);
+    bf16_t* dOs = Qs + NPAD * HD;
+    bf16_t* Ks = dOs + NPAD * HD;
+    bf16_t* Vs = Ks + NPAD * HD;
+    float* lse_s = reinterpret_cast<float*>(Vs + NPAD * HD);   // [NPAD] lse * log2(e), +inf past N
+    float* dl_s = lse_s + NPAD;                                // [NPAD] delta
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4, lq = lr >> 2, lp = lr & 3;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * HD, ld = 3 * D;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
+    const bf16_t* dobase = dout + (size_t)b * N * D + h * HD;
+    const bf16_t* obase = out + (size_t)b * N * D + h * HD;
+
+    {   // DMA fill, a piece = 8 rows x 128 B; tensor order in LDS: Q, dO, K, V
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(Qs));
+        const int prow = lane >> 3, ppos = lane & 7;
+        for (int pc = wave; pc < 4 * (NPAD / 8); pc += WAVES) {
+            const int which = pc / (NPAD / 8);
+            const int row = (pc - which * (NPAD / 8)) * 8 + prow;
+            const int srow = row < N ? row : N - 1;
+            const int ch = (ppos ^ (row & 7)) << 3;
+            const bf16_t* src = which == 1 ? dobase + (size_t)srow * D + ch
+                                           : base + (size_t)srow * ld + (which == 0 ? 0 : which - 1) * D + ch;
+            glds16_v(src, lds0 + (unsigned)pc * 1024u);
+        }
+    }
+    // delta and lse: item = (query row, 16-byte chunk), 8 neighbouring lanes share a row; NPAD * 8 items are an exact multiple
+    // of the block size.  All loads of a thread are issued before the first is used.
+    {
+        constexpr int ITEMS = NPAD * 8 / (WAVES * 64);
+        static_assert(ITEMS * WAVES * 64 == NPAD * 8, "items must divide evenly");
+        u32x4_t ra[ITEMS], rc[ITEMS];
+        float lv[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int it = tid + i * WAVES * 64;
+            int q = it >> 3;
+            q = q < N ? q : N - 1;
+            ra[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(dobase + (size_t)q * D + (it & 7) * 8));
+            rc[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(obase + (size_t)q * D + (it & 7) * 8));
+            lv[i] = lse[((size_t)b * H + h) * N + q];
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int it = tid + i * WAVES * 64;
+            const int q = it >> 3;
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part += __uint_as_float(ra[i][j] << 16) * __uint_as_float(rc[i][j] << 16);
+                part += __uint_as_float(ra[i][j] & 0xffff0000u) * __uint_as_float(rc[i][j] & 0xffff0000u);
+            }
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if ((it & 7) == 0) {
+                dl_s[q] = part;
+                lse_s[q] = q < N ? lv[i] * 1.44269504088896340736f : INFINITY;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const float c2 = scale * 1.44269504088896340736f;
+    const int foff0 = lr * HD + ((lg ^ (lr & 7)) << 3), foff1 = lr * HD + (((4 + lg) ^ (lr & 7)) << 3);   // b128 fragment of row 16t + lr
+    int toff[4];        // transposing-read offset of rows 4lg + lq (+16), columns 16dt + 4lp; same for every 32-row group
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) toff[dt] = swz(4 * lg + lq, dt * 16 + 4 * lp);
+
+    // ---------------------------------------------------------------- phase 1: dK, dV of the owned key tiles
+    {
+        bf16x8 kf[TPW][2], vf[TPW][2];
+        f32x4 dv[TPW][4], dk[TPW][4];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int kt = wave + i * WAVES;
+            const int ktc = kt < MAXT ? kt : MAXT - 1;
+            kf[i][0] = *reinterpret_cast<const bf16x8*>(&Ks[ktc * 16 * HD + foff0]);
+            kf[i][1] = *reinterpret_cast<const bf16x8*>(&Ks[ktc * 16 * HD + foff1]);
+            vf[i][0] = *reinterpret_cast<const bf16x8*>(&Vs[ktc * 16 * HD + foff0]);
+            vf[i][1] = *reinterpret_cast<const bf16x8*>(&Vs[ktc * 16 * HD + foff1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dv[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+        for (int st = 0; st < MAXT / 2; ++st) {
+            const bf16_t* Qp = Qs + st * 32 * HD;
+            const bf16_t* dOp = dOs + st * 32 * HD;
+            bf16x8 qf[2][2], dof[2][2], qtr[4], dotr[4];
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi) {
+                qf[qi][0] = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HD + foff0);
+                qf[qi][1] = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HD + foff1);
+                dof[qi][0] = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HD + foff0);
+                dof[qi][1] = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HD + foff1);
+            }
+            const f32x4 l0 = *reinterpret_cast<const f32x4*>(&lse_s[st * 32 + 4 * lg]);
+            const f32x4 l1 = *reinterpret_cast<const f32x4*>(&lse_s[st * 32 + 16 + 4 * lg]);
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(&dl_s[st * 32 + 4 * lg]);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(&dl_s[st * 32 + 16 + 4 * lg]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                qtr[dt] = tr_frag2(Qp + toff[dt], Qp + 16 * HD + toff[dt]);
+                dotr[dt] = tr_frag2(dOp + toff[dt], dOp + 16 * HD + toff[dt]);
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                if (wave + i * WAVES < MAXT) {
+                    f32x4 pt[2], ds[2];
+#pragma unroll
+                    for (int qi = 0; qi < 2; ++qi) {
+                        f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qi][ks], kf[i][ks], sacc, 0, 0, 0);
+                            dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[qi][ks], vf[i][ks], dpacc, 0, 0, 0);
+                        }
+                        // sacc[r] = S[q = 32st + 16qi + 4lg + r][key = lr]
+                        const f32x4 lq4 = qi ? l1 : l0, dq4 = qi ? d1 : d0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, -lq4[r]));
+                            pt[qi][r] = pp;
+                            ds[qi][r] = pp * (dpacc[r] - dq4[r]) * scale;
+                        }
+                    }
+                    const bf16x8 pa = pack8(pt[0], pt[1]);     // contraction slot (lg, j): q = 4lg + j | 16 + 4lg + j - 4
+                    const bf16x8 dsa = pack8(ds[0], ds[1]);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        dv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr[dt], pa, dv[i][dt], 0, 0, 0);
+                        dk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsa, dk[i][dt], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // lane holds dK^T / dV^T [d = 16dt + 4lg + r][key = lr]
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int key = (wave + i * WAVES) * 16 + lr;
+            if (wave + i * WAVES < MAXT && key < N) {
+                bf16_t* rowp = dqkv + ((size_t)b * N + key) * ld + h * HD + 4 * lg;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    uint2 wk, wv;
+                    wk.x = pack2bf(dk[i][dt][0], dk[i][dt][1]); wk.y = pack2bf(dk[i][dt][2], dk[i][dt][3]);
+                    wv.x = pack2bf(dv[i][dt][0], dv[i][dt][1]); wv.y = pack2bf(dv[i][dt][2], dv[i][dt][3]);
+                    *reinterpret_cast<uint2*>(rowp + D + dt * 16) = wk;
+                    *reinterpret_cast<uint2*>(rowp + 2 * D + dt * 16) = wv;
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- phase 2: dQ of the owned query tiles
+    f32x4 tail0[2];     // S^T accumulator start values of the last two key tiles: 0 for a real key, -inf for padding
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tail0[i][r] = ((MAXT - 2 + i) * 16 + 4 * lg + r < N) ? 0.f : -INFINITY;
+#pragma unroll 1
+    for (int qt = wave; qt * 16 < N; qt += WAVES) {
+        const int q = qt * 16 + lr;
+        bf16x8 qf[2], dof[2];
+        qf[0] = *reinterpret_cast<const bf16x8*>(&Qs[qt * 16 * HD + foff0]);
+        qf[1] = *reinterpret_cast<const bf16x8*>(&Qs[qt * 16 * HD + foff1]);
+        dof[0] = *reinterpret_cast<const bf16x8*>(&dOs[qt * 16 * HD + foff0]);
+        dof[1] = *reinterpret_cast<const bf16x8*>(&dOs[qt * 16 * HD + foff1]);
+        const float nl = -lse_s[q], dl = dl_s[q];
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(&Ks[foff0]), kf1 = *reinterpret_cast<const bf16x8*>(&Ks[foff1]);
+        bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(&Vs[foff0]), vf1 = *reinterpret_cast<const bf16x8*>(&Vs[foff1]);
+#pragma unroll
+        for (int u = 0; u < MAXT / 2; ++u) {
+            f32x4 ds[2];
+            bf16x8 ktr[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16_t* kp = Ks + u * 32 * HD + toff[dt];
+                ktr[dt] = tr_frag2(kp, kp + 16 * HD);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int t = 2 * u + e;
+                const bf16x8 a0 = kf0, a1 = kf1, b0 = vf0, b1 = vf1;
+                if (t + 1 < MAXT) {
+                    kf0 = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HD + foff0]);
+                    kf1 = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HD + foff1]);
+                    vf0 = *reinterpret_cast<const bf16x8*>(&Vs[(t + 1) * 16 * HD + foff0]);
+                    vf1 = *reinterpret_cast<const bf16x8*>(&Vs[(t + 1) * 16 * HD + foff1]);
+                }
+                f32x4 sacc = t < MAXT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (MAXT - 2)];
+                f32x4 dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], sacc, 0, 0, 0);
+                dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, dof[0], dpacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], sacc, 0, 0, 0);
+                dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, dof[1], dpacc, 0, 0, 0);
+                // sacc[r] = S^T[key = 16t + 4lg + r][q = lr]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, nl));
+                    ds[e][r] = pp * (dpacc[r] - dl) * scale;
+                }
+            }
+            const bf16x8 dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[dt], dsb, dq[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // dq[dt][r] = dQ^T[d = 16dt + 4lg + r][q = lr]
+        if (q < N) {
+            bf16_t* rowp = dqkv + ((size_t)b * N + q) * ld + h * HD + 4 * lg;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 w;
+                w.x = pack2bf(dq[dt][0], dq[dt][1]);
+                w.y = pack2bf(dq[dt][2], dq[dt][3]);
+                *reinterpret_cast<uint2*>(rowp + dt * 16) = w;
+            }
+        }
+    }
+}
+
 // dqkv[:, q columns] = bf16(dq_acc)
 __global__ void attn_dq_convert_kernel(const float* __restrict__ dq_acc, bf16_t* __restrict__ dqkv, size_t rows, int D) {
     const size_t total = rows * (size_t)(D / 4);
@@ -433,6 +681,29 @@ int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const
     VITK_REQUIRE(B > 0 && N > 0 && H > 0, "attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
     VITK_REQUIRE(vitk_aligned(qkv, 16) && vitk_aligned(out, 16) && vitk_aligned(dout, 16) && vitk_aligned(dqkv, 16),
                  "attention_bwd: pointers must be 16-byte aligned");
+    if (N <= KB_MAX) {
+        const int maxt = 2 * ((N + 31) / 32);
+        const size_t smem = (size_t)4 * maxt * 16 * HD * sizeof(bf16_t) + (size_t)2 * maxt * 16 * sizeof(float);
+        hipStream_t s = (hipStream_t)stream;
+        static bool attr_done[16] = {false};
+#define VITK_BWD_CASE(T, W)                                                                                                 \
+    case T: {                                                                                                               \
+        if (!attr_done[T]) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_res_kernel<T, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            if (e != hipSuccess) { vitk_set_error("attention_bwd: cannot set LDS size %zu: %s", smem, hipGetErrorString(e)); return VITK_ELAUNCH; } \
+            attr_done[T] = true;                                                                                            \
+        }                                                                                                                   \
+        attn_bwd_res_kernel<T, W><<<B * H, W * 64, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, \
+                                                              (bf16_t*)dqkv, N, H, scale);                                  \
+    } break;
+        switch (maxt) {
+            VITK_BWD_CASE(2, 2) VITK_BWD_CASE(4, 4) VITK_BWD_CASE(6, 6) VITK_BWD_CASE(8, 4) VITK_BWD_CASE(10, 5)
+            VITK_BWD_CASE(12, 6) VITK_BWD_CASE(14, 7)
+            default: vitk_set_error("attention_bwd: unsupported token count %d", N); return VITK_EINVAL;
+        }
+#undef VITK_BWD_CASE
+        return vitk_check_launch("attention_bwd");
+    }
     const int nkb = (N + KB_MAX - 1) / KB_MAX;
     const size_t need = vitk_attention_bwd_workspace(B, N, H);
     float* dq_acc = nullptr;
