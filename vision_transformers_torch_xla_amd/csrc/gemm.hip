@@ -317,16 +317,20 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
             voB[j] = (unsigned)((rb * p.ldb + sch * 8) * (int)sizeof(bf16_t));
         }
     };
-    auto stage = [&](int kstep, int par) {       // K-step kstep of the staging tile -> LDS buffer par (asynchronous)
+    // K-step kstep of the staging tile -> LDS buffer par (asynchronous), in two halves: the 8 DMA instructions of a step
+    // are issued 4 + 4, a phase apart (the activation panel first: it comes from HBM, the weight panel from L2), because a burst
+    // of 8 holds up the issuing wave for most of a phase (4 + 2 + 2 over three phases measured no better)
+    auto stageA = [&](int kstep, int par) {
         const unsigned dA = lds_base + (unsigned)(par * 2 * LTILE * sizeof(bf16_t)) + lds_stage;
-        const unsigned dB = dA + (unsigned)(LTILE * sizeof(bf16_t));
         const bf16_t* a = sA + kstep * GBK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(a, voA[j], dA + j * 8 * GBK * (unsigned)sizeof(bf16_t));
+    };
+    auto stageB = [&](int kstep, int par) {
+        const unsigned dB = lds_base + (unsigned)((par * 2 + 1) * LTILE * sizeof(bf16_t)) + lds_stage;
         const bf16_t* b = sB + kstep * GBK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(a, voA[j], dA + j * 8 * GBK * (unsigned)sizeof(bf16_t));
-            glds16(b, voB[j], dB + j * 8 * GBK * (unsigned)sizeof(bf16_t));
-        }
+        for (int j = 0; j < 4; ++j) glds16(b, voB[j], dB + j * 8 * GBK * (unsigned)sizeof(bf16_t));
     };
 
     // fragment read offsets (elements) inside a tile: row*64 + ((chunk ^ (row&7)) << 3); row&7 == lr&7 for every tile row
@@ -360,14 +364,17 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
     int v = blockIdx.x;
     int m0, n0, nm0 = 0, nn0 = 0;
     aim(v, m0, n0);
-    stage(0, 0);
+    stageA(0, 0);
+    stageB(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    stage(1, 1);
+    stageA(1, 1);
+    stageB(1, 1);
     ldB(fbE, lsm + LTILE, 0);
     ldA(faE, lsm, 0, 0);
     int par = 0;            // LDS buffer of the current K-step
+    int pend_k = -1, pend_par = 0;      // second half (B operand) of a request whose first half has been issued
     bool loose = false;     // the last VMEM operations of this wave are >= NTP_DRAIN output stores younger than every request
 
     for (;;) {
@@ -385,6 +392,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
             // Each phase: 16 MFMAs on fragments fetched a phase ago, interleaved (MFMAs first) with the reads for the next
             // phase, N-side fragments first because the next phase's first four MFMAs need all of them.
             // phase (0,0): fetch A rows 64..127 of ks 0
+            if (pend_k >= 0) { stageB(pend_k, pend_par); pend_k = -1; }
             mma(faE, fbE, 0);
             ldA(faO, cA, 0, 1);
 #pragma unroll
@@ -411,10 +419,12 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (kt + 2 < nk) {
-                stage(kt + 2, par);
+                stageA(kt + 2, par);
+                pend_k = kt + 2; pend_par = par;
             } else if (has_next) {
                 if (kt + 2 == nk) aim(v + G, nm0, nn0);
-                stage(kt + 2 - nk, par);
+                stageA(kt + 2 - nk, par);
+                pend_k = kt + 2 - nk; pend_par = par;
             }
             // phase (1,1): fetch the first fragments of the next K-step (after the last tile: stale LDS, never used)
             mma(faO, fbO, 1);
@@ -426,6 +436,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
             par ^= 1;
         }
 
+        if (pend_k >= 0) { stageB(pend_k, pend_par); pend_k = -1; }      // before the stores: vmcnt counts in issue order
         // Epilogue.  The MFMA layout (lane = row lr, 4 columns) would store 32-byte pieces of 16 rows per instruction, and
         // the store path is paid per lane-access, not per byte.  Transpose through this wave's private 4 KB of LDS instead
         // (fp32, so the arithmetic is unchanged): 16 rows x 64 columns at a time, read back as lane = (row lane/8, 8
@@ -749,25 +760,21 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
         voB[j] = (unsigned)((lrow * p.ldb + cb) * (int)sizeof(bf16_t));
     }
     const unsigned lds_stage = (unsigned)(wave * 4 * 1024);
-    auto stage = [&](int st, int par) {       // 64-row step st of this range -> LDS buffer par (asynchronous)
-        const unsigned dA = lds_base + (unsigned)(par * 2 * TNB_TILE * sizeof(bf16_t)) + lds_stage;
-        const unsigned dB = dA + (unsigned)(TNB_TILE * sizeof(bf16_t));
+    // 64-row step st of this range -> LDS buffer par (asynchronous); which = 0: the A half, 1: the B half (issued a phase
+    // apart: a burst of 8 DMA instructions holds up the issuing wave for most of a phase)
+    auto stage = [&](int st, int par, int which) {
+        const unsigned dst = lds_base + (unsigned)((par * 2 + which) * TNB_TILE * sizeof(bf16_t)) + lds_stage;
         const int mrow = (step0 + st) * 64;
-        const bf16_t* a = p.A + (size_t)mrow * p.lda;
-        const bf16_t* b = p.B + (size_t)mrow * p.ldb;
+        const bf16_t* src = which ? p.B + (size_t)mrow * p.ldb : p.A + (size_t)mrow * p.lda;
         if (mrow + 64 <= p.M) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                glds16(a, voA[j], dA + j * 1024);
-                glds16(b, voB[j], dB + j * 1024);
-            }
+            for (int j = 0; j < 4; ++j) glds16(src, which ? voB[j] : voA[j], dst + j * 1024);
         } else {       // ragged last step: rows >= M come from the zero row
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = mrow + (wave * 4 + j) * 2 + shalf < p.M;
                 const void* z = (const char*)vitk_zero_row + spos * 16;
-                glds16_v(ok ? (const void*)((const char*)a + voA[j]) : z, dA + j * 1024);
-                glds16_v(ok ? (const void*)((const char*)b + voB[j]) : z, dB + j * 1024);
+                glds16_v(ok ? (const void*)((const char*)src + (which ? voB[j] : voA[j])) : z, dst + j * 1024);
             }
         }
     };
@@ -817,11 +824,13 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
         }
     };
 
-    stage(0, 0);
+    stage(0, 0, 0);
+    stage(0, 0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    stage(1, 1);
+    stage(1, 1, 0);
+    stage(1, 1, 1);
     ldB(fbE, lsm + TNB_TILE, 0);
     ldA(faE, lsm, 0, 0);
 
@@ -833,6 +842,7 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
         const bf16_t* nB = nA + TNB_TILE;
         // same four-phase pipeline as the persistent gemm_nt kernel: 16 MFMAs on fragments fetched a phase ago, interleaved
         // with the transposing reads for the next phase
+        if (st >= 1 && st + 1 < nsteps) stage(st + 1, par ^ 1, 1);      // second half of the request made in the previous step
         mma(faE, fbE, 0);
         ldA(faO, cA, 0, 1);
 #pragma unroll
@@ -852,7 +862,7 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (st + 2 < nsteps) stage(st + 2, par);
+        if (st + 2 < nsteps) stage(st + 2, par, 0);
         mma(faO, fbO, 1);
         ldB(fbE, nB, 0);
         ldA(faE, nA, 0, 0);
