@@ -64,6 +64,13 @@ size_t vitk_layernorm_bwd_workspace(int M, int D);
 int vitk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                        const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate,
                        int M, int D, void* workspace, size_t workspace_bytes, void* stream);
+/* The same, and also dx_scaled_bf16[row] = rowscale[row / rows_per_group] * dx_bf16[row]: the gradient entering the next
+ * residual branch under stochastic depth (timm DropPath in Block.forward, models/vision_transformer.py:164-171), written
+ * in the same pass instead of by vitk_rowscale. */
+int vitk_layernorm_bwd_scaled(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                              const void* dres, void* dx, const float* rowscale, int rows_per_group, void* dx_scaled,
+                              float* dgamma, float* dbeta, int accumulate, int M, int D, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ---- GEMM, bf16 MFMA, fp32 accumulate.
  * vitk_gemm_nt: C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue.  Replaces nn.Linear forward/dgrad inside timm

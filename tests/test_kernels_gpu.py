@@ -58,6 +58,15 @@ def test_layernorm_fwd_bwd(device, M, D):
     assert rel_l2(dx2.float(), rb(xr.grad)) <= REL_TOL
     assert rel_l2(dgamma, 2 * gr.grad) <= REL_TOL
     assert rel_l2(dbeta, 2 * br.grad) <= REL_TOL
+    # fused stochastic-depth copy: bit-identical to scaling the stored bf16 dx in a separate pass
+    rpg = 3 if M % 3 == 0 else 1
+    sc = (torch.rand(M // rpg, generator=g) > 0.3).float() / 0.7
+    dg2, db2 = torch.zeros(D, device=device), torch.zeros(D, device=device)
+    dx3, dxs = ops.layernorm_bwd(dy.to(device), x.to(device), mean, rstd, gamma.to(device), dg2, db2, dres=dres.to(device),
+                                 rowscale=sc.to(device), rows_per_group=rpg)
+    assert torch.equal(dx3, dx)
+    assert torch.equal(dxs, ops.rowscale(dx, sc.to(device), rpg))
+    assert torch.equal(dxs.cpu(), (dx.float().cpu() * sc.repeat_interleave(rpg)[:, None]).to(bf16))
 
 
 # ----------------------------------------------------------------------------------------------------- GEMM

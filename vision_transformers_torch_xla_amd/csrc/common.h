@@ -80,6 +80,40 @@ static __device__ __forceinline__ float dgelu_erf(float x) {
     const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * u * u);
     return __builtin_fmaf(x, pdf, cdf);
 }
+// Two elements at a time: the polynomial runs on v_pk_fma_f32 (half the instructions of the VALU-bound GEMM epilogues).
+static __device__ __forceinline__ f32x2_t half_erfc_poly2(f32x2_t u) {
+    const f32x2_t c6 = {-1.3601819546238403e-06f, -1.3601819546238403e-06f}, c5 = {5.1214541599620134e-05f, 5.1214541599620134e-05f};
+    const f32x2_t c4 = {-0.0008435604977421463f, -0.0008435604977421463f}, c3 = {0.008160343393683434f, 0.008160343393683434f};
+    const f32x2_t c2 = {-0.05328623577952385f, -0.05328623577952385f}, c1 = {-0.4590398073196411f, -0.4590398073196411f};
+    const f32x2_t c0 = {-1.1510837078094482f, -1.1510837078094482f}, m1 = {-1.0f, -1.0f};
+    f32x2_t r = __builtin_elementwise_fma(c6, u, c5);
+    r = __builtin_elementwise_fma(r, u, c4);
+    r = __builtin_elementwise_fma(r, u, c3);
+    r = __builtin_elementwise_fma(r, u, c2);
+    r = __builtin_elementwise_fma(r, u, c1);
+    r = __builtin_elementwise_fma(r, u, c0);
+    r = __builtin_elementwise_fma(r, u, m1);
+    return (f32x2_t){__builtin_amdgcn_exp2f(r[0]), __builtin_amdgcn_exp2f(r[1])};
+}
+static __device__ __forceinline__ void gelu_erf2(float x0, float x1, float& y0, float& y1) {
+    const f32x2_t u = {fminf(fabsf(x0), 8.0f), fminf(fabsf(x1), 8.0f)};
+    const f32x2_t h = half_erfc_poly2(u);
+    const f32x2_t mx = {fmaxf(x0, 0.0f), fmaxf(x1, 0.0f)};
+    const f32x2_t y = __builtin_elementwise_fma(-u, h, mx);
+    y0 = y[0]; y1 = y[1];
+}
+static __device__ __forceinline__ void dgelu_erf2(float x0, float x1, float& y0, float& y1) {
+    const f32x2_t u = {fminf(fabsf(x0), 8.0f), fminf(fabsf(x1), 8.0f)};
+    const f32x2_t h = half_erfc_poly2(u);
+    const f32x2_t k = {-0.72134752044448170368f, -0.72134752044448170368f};
+    const f32x2_t e = (k * u) * u;
+    const f32x2_t x = {x0, x1};
+    const f32x2_t xs = x * (f32x2_t){0.39894228040143267794f, 0.39894228040143267794f};
+    const f32x2_t pdf = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    const f32x2_t cdf = {0.5f + copysignf(0.5f - h[0], x0), 0.5f + copysignf(0.5f - h[1], x1)};
+    const f32x2_t y = __builtin_elementwise_fma(xs, pdf, cdf);
+    y0 = y[0]; y1 = y[1];
+}
 
 // load 8 bf16 (16 B) as floats
 static __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
@@ -89,11 +123,12 @@ static __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
     v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
     v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
 }
-static __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+static __device__ __forceinline__ uint4 pack8_bf16(const float (&v)[8]) {
     uint4 r;
     r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]); r.z = pack2bf(v[4], v[5]); r.w = pack2bf(v[6], v[7]);
-    *reinterpret_cast<uint4*>(p) = r;
+    return r;
 }
+static __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) { *reinterpret_cast<uint4*>(p) = pack8_bf16(v); }
 
 // ---- host side
 void vitk_set_error(const char* fmt, ...);

@@ -122,8 +122,7 @@ static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float 
 #pragma unroll
         for (int j = 0; j < W; j += 2) {
             hp[j / 2] = pack2bf(v[j], v[j + 1]);
-            a[j] = gelu_erf(__uint_as_float(hp[j / 2] << 16));
-            a[j + 1] = gelu_erf(__uint_as_float(hp[j / 2] & 0xffff0000u));
+            gelu_erf2(__uint_as_float(hp[j / 2] << 16), __uint_as_float(hp[j / 2] & 0xffff0000u), a[j], a[j + 1]);
         }
         bf16_t* cp = (bf16_t*)p.C + (size_t)m * p.ldc + n;
         if (W == 4) {
@@ -147,7 +146,12 @@ static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float 
         float h[W];
         if (side == nullptr) load_bf16<W>(p.aux + (size_t)m * p.ldaux + n, h);
 #pragma unroll
-        for (int j = 0; j < W; ++j) v[j] *= dgelu_erf(side ? side[j] : h[j]);
+        for (int j = 0; j < W; j += 2) {
+            float g0, g1;
+            dgelu_erf2(side ? side[j] : h[j], side ? side[j + 1] : h[j + 1], g0, g1);
+            v[j] *= g0;
+            v[j + 1] *= g1;
+        }
         store_bf16<W>((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
     }
 }

@@ -65,13 +65,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 
 // Backward.  Each wave keeps per-lane column partials of dgamma/dbeta over all the rows it visits; the block
 // folds its 4 waves through LDS and writes one partial row; ln_bwd_reduce_kernel sums the partial rows in a
-// fixed order (deterministic).
-template <int NV>
+// fixed order (deterministic).  Every global load of a row (x, dy, the residual gradient) is issued before the
+// first is used.  With rowscale the kernel also writes dxs = rowscale[row / rows_per_group] * dx, the gradient
+// that enters the next residual branch under stochastic depth (one extra store instead of a separate pass).
+typedef __attribute__((ext_vector_type(4))) unsigned ln_u4;
+static __device__ __forceinline__ void ln_unpack(const ln_u4 r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+template <int NV, bool RES, bool SCALED>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const bf16_t* __restrict__ dres,
-                                                      bf16_t* __restrict__ dx, float* __restrict__ partial /*[grid][2][D]*/,
-                                                      int M, int D) {
+                                                      bf16_t* __restrict__ dx, const float* __restrict__ rowscale,
+                                                      int rows_per_group, bf16_t* __restrict__ dxs,
+                                                      float* __restrict__ partial /*[grid][2][D]*/, int M, int D) {
     extern __shared__ __attribute__((aligned(16))) float ln_smem[];   // [4][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D >> 3;
@@ -85,30 +96,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
     for (int row = blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * LN_ROWS_PER_BLOCK) {
         const size_t off = (size_t)row * D;
+        ln_u4 rx[NV], rd[NV], rr[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            const int cc = c < nvec ? c : 0;        // lanes past the row re-read chunk 0 and ignore it
+            rx[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(x + off + 8 * cc));
+            rd[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dy + off + 8 * cc));
+            if (RES) rr[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dres + off + 8 * cc));
+        }
         const float mu = mean[row], rs = rstd[row];
+        float sc = 1.0f;
+        if (SCALED) sc = rowscale[row / rows_per_group];
         float xh[NV][8], gd[NV][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
-            if (c < nvec) {
-                float xv[8], dv[8];
-                load8(x + off + 8 * c, xv);
-                load8(dy + off + 8 * c, dv);
+            float xv[8], dv[8];
+            ln_unpack(rx[i], xv);
+            ln_unpack(rd[i], dv);
+            const bool ok = c < nvec;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float h = (xv[j] - mu) * rs;
-                    xh[i][j] = h;
-                    dg[i][j] += dv[j] * h;
-                    db[i][j] += dv[j];
-                    const float t = dv[j] * g[i][j];
-                    gd[i][j] = t;
-                    s1 += t;
-                    s2 += t * h;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { xh[i][j] = 0.f; gd[i][j] = 0.f; }
+            for (int j = 0; j < 8; ++j) {
+                const float h = ok ? (xv[j] - mu) * rs : 0.f;
+                const float d = ok ? dv[j] : 0.f;
+                xh[i][j] = h;
+                dg[i][j] += d * h;
+                db[i][j] += d;
+                const float t = d * g[i][j];
+                gd[i][j] = t;
+                s1 += t;
+                s2 += t * h;
             }
         }
         const float c1 = wave_sum(s1) * invD;
@@ -120,13 +139,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = rs * (gd[i][j] - c1 - xh[i][j] * c2);
-                if (dres != nullptr) {
+                if (RES) {
                     float r[8];
-                    load8(dres + off + 8 * c, r);
+                    ln_unpack(rr[i], r);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] += r[j];
                 }
                 store8(dx + off + 8 * c, o);
+                if (SCALED) {
+                    // scale the bf16 value that was just stored, as a separate pass over dx would
+                    const uint4 w = pack8_bf16(o);
+                    float q[8];
+                    ln_unpack((ln_u4){w.x, w.y, w.z, w.w}, q);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) q[j] *= sc;
+                    store8(dxs + off + 8 * c, q);
+                }
             }
         }
     }
@@ -198,13 +226,15 @@ size_t vitk_layernorm_bwd_workspace(int M, int D) {
     return (size_t)ln_bwd_grid(M) * 2 * (size_t)D * sizeof(float);
 }
 
-int vitk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
-                       const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate, int M, int D,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+static int ln_bwd_impl(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const void* dres,
+                       void* dx, const float* rowscale, int rows_per_group, void* dxs, float* dgamma, float* dbeta, int accumulate,
+                       int M, int D, void* workspace, size_t workspace_bytes, void* stream) {
     VITK_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
     VITK_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 1024, "layernorm_bwd: need M>0, D%%8==0, D<=1024 (M=%d D=%d)", M, D);
     VITK_REQUIRE(vitk_aligned(dy, 16) && vitk_aligned(x, 16) && vitk_aligned(dx, 16) && (!dres || vitk_aligned(dres, 16)),
                  "layernorm_bwd: pointers must be 16-byte aligned");
+    VITK_REQUIRE(!rowscale || (dxs && rows_per_group > 0 && vitk_aligned(dxs, 16)),
+                 "layernorm_bwd: rowscale needs dx_scaled (16-byte aligned) and rows_per_group > 0");
     if (workspace_bytes < vitk_layernorm_bwd_workspace(M, D)) {
         vitk_set_error("layernorm_bwd: workspace %zu < %zu", workspace_bytes, vitk_layernorm_bwd_workspace(M, D));
         return VITK_ENOSPC;
@@ -213,16 +243,41 @@ int vitk_layernorm_bwd(const void* dy, const void* x, const float* mean, const f
     const int grid = ln_bwd_grid(M);
     const size_t smem = (size_t)LN_ROWS_PER_BLOCK * 2 * D * sizeof(float);
     float* partial = (float*)workspace;
-    if (D <= 512)
-        ln_bwd_kernel<1><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma,
-                                                  (const bf16_t*)dres, (bf16_t*)dx, partial, M, D);
-    else
-        ln_bwd_kernel<2><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma,
-                                                  (const bf16_t*)dres, (bf16_t*)dx, partial, M, D);
+#define VITK_LN_BWD(NV, R, S)                                                                                                  \
+    ln_bwd_kernel<NV, R, S><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, \
+                                                    (bf16_t*)dx, rowscale, rows_per_group, (bf16_t*)dxs, partial, M, D)
+    const int sel = (D <= 512 ? 0 : 4) + (dres ? 2 : 0) + (rowscale ? 1 : 0);
+    switch (sel) {
+        case 0: VITK_LN_BWD(1, false, false); break;
+        case 1: VITK_LN_BWD(1, false, true); break;
+        case 2: VITK_LN_BWD(1, true, false); break;
+        case 3: VITK_LN_BWD(1, true, true); break;
+        case 4: VITK_LN_BWD(2, false, false); break;
+        case 5: VITK_LN_BWD(2, false, true); break;
+        case 6: VITK_LN_BWD(2, true, false); break;
+        default: VITK_LN_BWD(2, true, true); break;
+    }
+#undef VITK_LN_BWD
     int rc = vitk_check_launch("layernorm_bwd");
     if (rc) return rc;
     ln_bwd_reduce_kernel<<<(2 * D + 15) / 16, 1024, 0, s>>>(partial, grid, D, dgamma, dbeta, accumulate);
     return vitk_check_launch("layernorm_bwd_reduce");
+}
+
+int vitk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                       const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate, int M, int D,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    return ln_bwd_impl(dy, x, mean, rstd, gamma, dres, dx, nullptr, 0, nullptr, dgamma, dbeta, accumulate, M, D, workspace,
+                       workspace_bytes, stream);
+}
+
+int vitk_layernorm_bwd_scaled(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                              const void* dres, void* dx, const float* rowscale, int rows_per_group, void* dx_scaled,
+                              float* dgamma, float* dbeta, int accumulate, int M, int D, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    VITK_REQUIRE(rowscale && dx_scaled, "layernorm_bwd_scaled: rowscale and dx_scaled are required");
+    return ln_bwd_impl(dy, x, mean, rstd, gamma, dres, dx, rowscale, rows_per_group, dx_scaled, dgamma, dbeta, accumulate, M, D,
+                       workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

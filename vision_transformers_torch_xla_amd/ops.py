@@ -61,8 +61,10 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, accumulate=False, ws: Workspace = None, dx=None):
-    """Returns dx bf16 [M,D] (= LN backward of dy, plus dres when given); writes/accumulates dgamma, dbeta (fp32 [D])."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, accumulate=False, ws: Workspace = None, dx=None,
+                  rowscale=None, rows_per_group=0):
+    """Returns dx bf16 [M,D] (= LN backward of dy, plus dres when given); writes/accumulates dgamma, dbeta (fp32 [D]).
+    With rowscale (fp32 [M / rows_per_group]) returns (dx, dx_scaled) where dx_scaled[row] = rowscale[group] * dx[row]."""
     _chk(dy, bf16, "dy"); _chk(x, bf16, "x"); _chk(gamma, f32, "gamma"); _chk(dgamma, f32, "dgamma"); _chk(dbeta, f32, "dbeta")
     if dres is not None:
         _chk(dres, bf16, "dres")
@@ -72,6 +74,13 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, accumulate
     w = (ws or _default_ws).get(need, x.device)
     if dx is None:
         dx = torch.empty_like(x)
+    if rowscale is not None:
+        _chk(rowscale, f32, "rowscale")
+        dxs = torch.empty_like(x)
+        check(lib.vitk_layernorm_bwd_scaled(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres), _ptr(dx), _ptr(rowscale),
+                                            int(rows_per_group), _ptr(dxs), _ptr(dgamma), _ptr(dbeta), int(accumulate), M, D, _ptr(w),
+                                            w.numel(), _stream()), "layernorm_bwd_scaled")
+        return dx, dxs
     check(lib.vitk_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres), _ptr(dx), _ptr(dgamma),
                                  _ptr(dbeta), int(accumulate), M, D, _ptr(w), w.numel(), _stream()), "layernorm_bwd")
     return dx

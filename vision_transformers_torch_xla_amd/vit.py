@@ -450,6 +450,7 @@ class VisionTransformer(nn.Module):
             hook(self._head_end, False)
 
         layers = saved["layers"]
+        dout_mlp = None      # s2 * dx of the block about to be processed, when the LayerNorm backward below it already wrote it
         for i in reversed(range(self.depth)):
             blk = self.blocks[i]
             pre = f"blocks.{i}."
@@ -457,24 +458,29 @@ class VisionTransformer(nn.Module):
             layers[i] = None
             dx_in = dx
             # ---- MLP branch: x3 = x2 + s2 * fc2(gelu(fc1(ln2(x2))))
-            dout = ops.rowscale(dx, s2, N) if s2 is not None else dx
+            dout = dx if s2 is None else (dout_mlp if dout_mlp is not None else ops.rowscale(dx, s2, N))
+            dout_mlp = None
             ops.gemm_tn(dout, a, g[pre + "mlp.fc2.weight"], dbias=g[pre + "mlp.fc2.bias"], accumulate=acc, ws=ws)
             dh = ops.gemm_nt(dout, wt[pre + "mlp.fc2.weight"], epilogue=EPI_DGELU, aux=h)
             ops.gemm_tn(dh, y2, g[pre + "mlp.fc1.weight"], dbias=g[pre + "mlp.fc1.bias"], accumulate=acc, ws=ws)
             dy2 = ops.gemm_nt(dh, wt[pre + "mlp.fc1.weight"])
             del dh
+            # the LayerNorm backward also writes the stochastic-depth-scaled copy its consumer needs (s1 * dx2 here)
             dx2 = ops.layernorm_bwd(dy2, x2, m2, r2, blk.norm2.weight, g[pre + "norm2.weight"], g[pre + "norm2.bias"], dres=dx,
-                                    accumulate=acc, ws=ws)
+                                    accumulate=acc, ws=ws, rowscale=s1, rows_per_group=N)
             # ---- attention branch: x2 = x + s1 * proj(attn(qkv(ln1(x))))
-            dout = ops.rowscale(dx2, s1, N) if s1 is not None else dx2
+            dx2, dout = dx2 if s1 is not None else (dx2, dx2)
             ops.gemm_tn(dout, o, g[pre + "attn.proj.weight"], dbias=g[pre + "attn.proj.bias"], accumulate=acc, ws=ws)
             do = ops.gemm_nt(dout, wt[pre + "attn.proj.weight"])
             dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, scale, ws=ws)
             ops.gemm_tn(dqkv, y1, g[pre + "attn.qkv.weight"], dbias=g[pre + "attn.qkv.bias"], accumulate=acc, ws=ws)
             dy1 = ops.gemm_nt(dqkv, wt[pre + "attn.qkv.weight"])
             del dqkv
+            s2_below = layers[i - 1][14] if i > 0 else None       # s2 of the next block to be processed
             dx = ops.layernorm_bwd(dy1, x, m1, r1, blk.norm1.weight, g[pre + "norm1.weight"], g[pre + "norm1.bias"], dres=dx2,
-                                   accumulate=acc, ws=ws)
+                                   accumulate=acc, ws=ws, rowscale=s2_below, rows_per_group=N)
+            if s2_below is not None:
+                dx, dout_mlp = dx
             if self._bwd_taps is not None:       # tests: the gradients entering / between / leaving the two half-blocks
                 self._bwd_taps[i] = dict(dx_in=dx_in, dx2=dx2, dx=dx, x=x, x2=x2)
             if hook is not None:
