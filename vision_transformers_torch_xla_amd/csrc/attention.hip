@@ -379,27 +379,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------- backward, resident variant
-// For heads of at most 224 tokens everything a head needs fits in LDS at once: Q, K, V, dO as [NPAD][64] images (chunk
-// XOR-swizzled by row & 7, filled by DMA) plus lse and delta = rowsum(dO * O) per query.  The kernel then runs two
-// barrier-free phases and recomputes the scores in the second instead of passing dS between waves:
+// For heads of at most 224 tokens.  Two barrier-free phases; the scores are recomputed in the second instead of passing dS
+// between waves:
 //   phase 1, a wave owns key tiles:   S = Q K^T, dP = dO V^T (key on the lane), P = 2^(S c - lse'), dS = P (dP - delta) scale,
 //                                     dV^T += dO^T P, dK^T += Q^T dS   (Q^T, dO^T by transposing reads)
 //   phase 2, a wave owns query tiles: S^T = K Q^T, dP^T = V dO^T (query on the lane), same P and dS, dQ^T += K^T dS^T.
+// What all waves share goes through LDS ([NPAD][64] images, chunk XOR-swizzled by row & 7, filled by DMA): Q and dO in
+// phase 1, K and V in phase 2 - the SAME 56 KB, refilled between the phases - while what only one wave needs (its own K, V
+// rows in phase 1, its own Q, dO rows in phase 2) comes straight from global memory into registers.  58 KB of LDS and 128
+// registers let two workgroups (14 waves) share a CU, so one head's loads and barriers hide under the other's MFMAs.
+// The owned key tiles of phase 1 are processed one after the other, each step in two stages that reuse the same registers
+// (b128 fragments of Q, dO for S and dP; then their transposed fragments for dV, dK).
 // Padding: query rows >= N carry lse' = +inf, so P = dS = 0 there; key rows >= N start the S^T accumulators of phase 2 at
 // -inf (tiles below MAXT-2 are all real keys); in phase 1 padded keys only feed dK/dV rows that are never stored.
 // MAXT = 2 * ceil(N / 32) key tiles is a template parameter: no run-time loop bounds.
-template <int MAXT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                                     const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                                     bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+template <int MAXT, int WAVES, int WPE>
+__global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                                       const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                       bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
     constexpr int NPAD = MAXT * 16;
     constexpr int TPW = (MAXT + WAVES - 1) / WAVES;        // key tiles (phase 1) / query tiles (phase 2) per wave
-    bf16_t* Qs = reinterpret_cast<bf16_t*>(attn_smem);
-    bf16_t* dOs = Qs + NPAD * HD;
-    bf16_t* Ks = dOs + NPAD * HD;
-    bf16_t* Vs = Ks + NPAD * HD;
-    float* lse_s = reinterpret_cast<float*>(Vs + NPAD * HD);   // [NPAD] lse * log2(e), +inf past N
+    bf16_t* R0 = reinterpret_cast<bf16_t*>(attn_smem);     // Q, then K
+    bf16_t* R1 = R0 + NPAD * HD;                            // dO, then V
+    float* lse_s = reinterpret_cast<float*>(R1 + NPAD * HD);   // [NPAD] lse * log2(e), +inf past N
     float* dl_s = lse_s + NPAD;                                // [NPAD] delta
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -410,20 +413,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_res_kernel(const bf16_
     const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
     const bf16_t* dobase = dout + (size_t)b * N * D + h * HD;
     const bf16_t* obase = out + (size_t)b * N * D + h * HD;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(R0));
 
-    {   // DMA fill, a piece = 8 rows x 128 B; tensor order in LDS: Q, dO, K, V
-        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(Qs));
+    // DMA fill of the two images, a piece = 8 rows x 128 B: first = false: (Q, dO), true: (K, V)
+    auto fill = [&](bool second) {
         const int prow = lane >> 3, ppos = lane & 7;
-        for (int pc = wave; pc < 4 * (NPAD / 8); pc += WAVES) {
-            const int which = pc / (NPAD / 8);
+        for (int pc = wave; pc < 2 * (NPAD / 8); pc += WAVES) {
+            const int which = pc >= NPAD / 8 ? 1 : 0;
             const int row = (pc - which * (NPAD / 8)) * 8 + prow;
             const int srow = row < N ? row : N - 1;
             const int ch = (ppos ^ (row & 7)) << 3;
-            const bf16_t* src = which == 1 ? dobase + (size_t)srow * D + ch
-                                           : base + (size_t)srow * ld + (which == 0 ? 0 : which - 1) * D + ch;
+            const bf16_t* src = second ? base + (size_t)srow * ld + (1 + which) * D + ch
+                                       : (which ? dobase + (size_t)srow * D + ch : base + (size_t)srow * ld + ch);
             glds16_v(src, lds0 + (unsigned)pc * 1024u);
         }
-    }
+    };
+    fill(false);
     // delta and lse: item = (query row, 16-byte chunk), 8 neighbouring lanes share a row; NPAD * 8 items are an exact multiple
     // of the block size.  All loads of a thread are issued before the first is used.
     {
@@ -468,92 +473,103 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_res_kernel(const bf16_
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) toff[dt] = swz(4 * lg + lq, dt * 16 + 4 * lp);
 
-    // ---------------------------------------------------------------- phase 1: dK, dV of the owned key tiles
-    {
-        bf16x8 kf[TPW][2], vf[TPW][2];
-        f32x4 dv[TPW][4], dk[TPW][4];
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int kt = wave + i * WAVES;
-            const int ktc = kt < MAXT ? kt : MAXT - 1;
-            kf[i][0] = *reinterpret_cast<const bf16x8*>(&Ks[ktc * 16 * HD + foff0]);
-            kf[i][1] = *reinterpret_cast<const bf16x8*>(&Ks[ktc * 16 * HD + foff1]);
-            vf[i][0] = *reinterpret_cast<const bf16x8*>(&Vs[ktc * 16 * HD + foff0]);
-            vf[i][1] = *reinterpret_cast<const bf16x8*>(&Vs[ktc * 16 * HD + foff1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { dv[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // ---------------------------------------------------------------- phase 1: dK, dV of the owned key tiles (R0 = Q, R1 = dO)
+#pragma unroll 1
+    for (int kt = wave; kt < MAXT; kt += WAVES) {
+        bf16x8 kf[2], vf[2];
+        {
+            int key = kt * 16 + lr;
+            key = key < N ? key : N - 1;
+            const bf16_t* kp = base + (size_t)key * ld + D + 8 * lg;
+            kf[0] = *reinterpret_cast<const bf16x8*>(kp);
+            kf[1] = *reinterpret_cast<const bf16x8*>(kp + 32);
+            vf[0] = *reinterpret_cast<const bf16x8*>(kp + D);
+            vf[1] = *reinterpret_cast<const bf16x8*>(kp + D + 32);
         }
+        f32x4 dv[4], dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
         for (int st = 0; st < MAXT / 2; ++st) {
-            const bf16_t* Qp = Qs + st * 32 * HD;
-            const bf16_t* dOp = dOs + st * 32 * HD;
-            bf16x8 qf[2][2], dof[2][2], qtr[4], dotr[4];
+            const bf16_t* Qp = R0 + st * 32 * HD;
+            const bf16_t* dOp = R1 + st * 32 * HD;
+            bf16x8 pa, dsa;
+            {   // stage 1: scores and their gradient for 32 queries x 16 keys
+                f32x4 pt[2], ds[2];
+                const f32x4 l0 = *reinterpret_cast<const f32x4*>(&lse_s[st * 32 + 4 * lg]);
+                const f32x4 l1 = *reinterpret_cast<const f32x4*>(&lse_s[st * 32 + 16 + 4 * lg]);
+                const f32x4 d0 = *reinterpret_cast<const f32x4*>(&dl_s[st * 32 + 4 * lg]);
+                const f32x4 d1 = *reinterpret_cast<const f32x4*>(&dl_s[st * 32 + 16 + 4 * lg]);
 #pragma unroll
-            for (int qi = 0; qi < 2; ++qi) {
-                qf[qi][0] = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HD + foff0);
-                qf[qi][1] = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HD + foff1);
-                dof[qi][0] = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HD + foff0);
-                dof[qi][1] = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HD + foff1);
-            }
-            const f32x4 l0 = *reinterpret_cast<const f32x4*>(&lse_s[st * 32 + 4 * lg]);
-            const f32x4 l1 = *reinterpret_cast<const f32x4*>(&lse_s[st * 32 + 16 + 4 * lg]);
-            const f32x4 d0 = *reinterpret_cast<const f32x4*>(&dl_s[st * 32 + 4 * lg]);
-            const f32x4 d1 = *reinterpret_cast<const f32x4*>(&dl_s[st * 32 + 16 + 4 * lg]);
+                for (int qi = 0; qi < 2; ++qi) {
+                    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HD + foff0);
+                    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HD + foff1);
+                    const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HD + foff0);
+                    const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HD + foff1);
+                    f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf[0], sacc, 0, 0, 0);
+                    dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, vf[0], dpacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf[1], sacc, 0, 0, 0);
+                    dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, vf[1], dpacc, 0, 0, 0);
+                    // sacc[r] = S[q = 32st + 16qi + 4lg + r][key = lr]
+                    const f32x4 lq4 = qi ? l1 : l0, dq4 = qi ? d1 : d0;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                qtr[dt] = tr_frag2(Qp + toff[dt], Qp + 16 * HD + toff[dt]);
-                dotr[dt] = tr_frag2(dOp + toff[dt], dOp + 16 * HD + toff[dt]);
-            }
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                if (wave + i * WAVES < MAXT) {
-                    f32x4 pt[2], ds[2];
-#pragma unroll
-                    for (int qi = 0; qi < 2; ++qi) {
-                        f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qi][ks], kf[i][ks], sacc, 0, 0, 0);
-                            dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[qi][ks], vf[i][ks], dpacc, 0, 0, 0);
-                        }
-                        // sacc[r] = S[q = 32st + 16qi + 4lg + r][key = lr]
-                        const f32x4 lq4 = qi ? l1 : l0, dq4 = qi ? d1 : d0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, -lq4[r]));
-                            pt[qi][r] = pp;
-                            ds[qi][r] = pp * (dpacc[r] - dq4[r]) * scale;
-                        }
-                    }
-                    const bf16x8 pa = pack8(pt[0], pt[1]);     // contraction slot (lg, j): q = 4lg + j | 16 + 4lg + j - 4
-                    const bf16x8 dsa = pack8(ds[0], ds[1]);
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        dv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr[dt], pa, dv[i][dt], 0, 0, 0);
-                        dk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsa, dk[i][dt], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) {
+                        const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, -lq4[r]));
+                        pt[qi][r] = pp;
+                        ds[qi][r] = pp * (dpacc[r] - dq4[r]) * scale;
                     }
                 }
+                pa = pack8(pt[0], pt[1]);     // contraction slot (lg, j): q = 4lg + j | 16 + 4lg + j - 4
+                dsa = pack8(ds[0], ds[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // stage 2: dV^T += dO^T P, dK^T += Q^T dS
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 dotr = tr_frag2(dOp + toff[dt], dOp + 16 * HD + toff[dt]);
+                const bf16x8 qtr = tr_frag2(Qp + toff[dt], Qp + 16 * HD + toff[dt]);
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr, pa, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsa, dk[dt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         // lane holds dK^T / dV^T [d = 16dt + 4lg + r][key = lr]
+        const int key = kt * 16 + lr;
+        if (key < N) {
+            bf16_t* rowp = dqkv + ((size_t)b * N + key) * ld + h * HD + 4 * lg;
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int key = (wave + i * WAVES) * 16 + lr;
-            if (wave + i * WAVES < MAXT && key < N) {
-                bf16_t* rowp = dqkv + ((size_t)b * N + key) * ld + h * HD + 4 * lg;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    uint2 wk, wv;
-                    wk.x = pack2bf(dk[i][dt][0], dk[i][dt][1]); wk.y = pack2bf(dk[i][dt][2], dk[i][dt][3]);
-                    wv.x = pack2bf(dv[i][dt][0], dv[i][dt][1]); wv.y = pack2bf(dv[i][dt][2], dv[i][dt][3]);
-                    *reinterpret_cast<uint2*>(rowp + D + dt * 16) = wk;
-                    *reinterpret_cast<uint2*>(rowp + 2 * D + dt * 16) = wv;
-                }
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 wk, wv;
+                wk.x = pack2bf(dk[dt][0], dk[dt][1]); wk.y = pack2bf(dk[dt][2], dk[dt][3]);
+                wv.x = pack2bf(dv[dt][0], dv[dt][1]); wv.y = pack2bf(dv[dt][2], dv[dt][3]);
+                *reinterpret_cast<uint2*>(rowp + D + dt * 16) = wk;
+                *reinterpret_cast<uint2*>(rowp + 2 * D + dt * 16) = wv;
             }
         }
     }
+    (void)TPW;
 
-    // ---------------------------------------------------------------- phase 2: dQ of the owned query tiles
+    // every wave is done with Q and dO: refill the same LDS with K and V
+    __syncthreads();
+    fill(true);
+    // this wave's first query tile travels with the refill
+    auto load_q = [&](int qt, bf16x8 (&qf)[2], bf16x8 (&dof)[2]) {
+        int q = qt * 16 + lr;
+        q = q < N ? q : N - 1;
+        const bf16_t* qp = base + (size_t)q * ld + 8 * lg;
+        const bf16_t* dp = dobase + (size_t)q * D + 8 * lg;
+        qf[0] = *reinterpret_cast<const bf16x8*>(qp);
+        qf[1] = *reinterpret_cast<const bf16x8*>(qp + 32);
+        dof[0] = *reinterpret_cast<const bf16x8*>(dp);
+        dof[1] = *reinterpret_cast<const bf16x8*>(dp + 32);
+    };
+    bf16x8 qf[2], dof[2];
+    load_q(wave, qf, dof);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase 2: dQ of the owned query tiles (R0 = K, R1 = V)
     f32x4 tail0[2];     // S^T accumulator start values of the last two key tiles: 0 for a real key, -inf for padding
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -562,35 +578,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_res_kernel(const bf16_
 #pragma unroll 1
     for (int qt = wave; qt * 16 < N; qt += WAVES) {
         const int q = qt * 16 + lr;
-        bf16x8 qf[2], dof[2];
-        qf[0] = *reinterpret_cast<const bf16x8*>(&Qs[qt * 16 * HD + foff0]);
-        qf[1] = *reinterpret_cast<const bf16x8*>(&Qs[qt * 16 * HD + foff1]);
-        dof[0] = *reinterpret_cast<const bf16x8*>(&dOs[qt * 16 * HD + foff0]);
-        dof[1] = *reinterpret_cast<const bf16x8*>(&dOs[qt * 16 * HD + foff1]);
         const float nl = -lse_s[q], dl = dl_s[q];
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(&Ks[foff0]), kf1 = *reinterpret_cast<const bf16x8*>(&Ks[foff1]);
-        bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(&Vs[foff0]), vf1 = *reinterpret_cast<const bf16x8*>(&Vs[foff1]);
+        bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(&R0[foff0]), kf1 = *reinterpret_cast<const bf16x8*>(&R0[foff1]);
+        bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(&R1[foff0]), vf1 = *reinterpret_cast<const bf16x8*>(&R1[foff1]);
 #pragma unroll
         for (int u = 0; u < MAXT / 2; ++u) {
             f32x4 ds[2];
-            bf16x8 ktr[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16_t* kp = Ks + u * 32 * HD + toff[dt];
-                ktr[dt] = tr_frag2(kp, kp + 16 * HD);
-            }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int t = 2 * u + e;
                 const bf16x8 a0 = kf0, a1 = kf1, b0 = vf0, b1 = vf1;
                 if (t + 1 < MAXT) {
-                    kf0 = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HD + foff0]);
-                    kf1 = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HD + foff1]);
-                    vf0 = *reinterpret_cast<const bf16x8*>(&Vs[(t + 1) * 16 * HD + foff0]);
-                    vf1 = *reinterpret_cast<const bf16x8*>(&Vs[(t + 1) * 16 * HD + foff1]);
+                    kf0 = *reinterpret_cast<const bf16x8*>(&R0[(t + 1) * 16 * HD + foff0]);
+                    kf1 = *reinterpret_cast<const bf16x8*>(&R0[(t + 1) * 16 * HD + foff1]);
+                    vf0 = *reinterpret_cast<const bf16x8*>(&R1[(t + 1) * 16 * HD + foff0]);
+                    vf1 = *reinterpret_cast<const bf16x8*>(&R1[(t + 1) * 16 * HD + foff1]);
                 }
                 f32x4 sacc = t < MAXT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (MAXT - 2)];
                 f32x4 dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -607,9 +612,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_res_kernel(const bf16_
             }
             const bf16x8 dsb = pack8(ds[0], ds[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[dt], dsb, dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16_t* kp = R0 + u * 32 * HD + toff[dt];
+                const bf16x8 ktr = tr_frag2(kp, kp + 16 * HD);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dsb, dq[dt], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if ((qt + WAVES) * 16 < N) load_q(qt + WAVES, qf, dof);
         // dq[dt][r] = dQ^T[d = 16dt + 4lg + r][q = lr]
         if (q < N) {
             bf16_t* rowp = dqkv + ((size_t)b * N + q) * ld + h * HD + 4 * lg;
@@ -683,22 +693,22 @@ int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const
                  "attention_bwd: pointers must be 16-byte aligned");
     if (N <= KB_MAX) {
         const int maxt = 2 * ((N + 31) / 32);
-        const size_t smem = (size_t)4 * maxt * 16 * HD * sizeof(bf16_t) + (size_t)2 * maxt * 16 * sizeof(float);
+        const size_t smem = (size_t)2 * maxt * 16 * HD * sizeof(bf16_t) + (size_t)2 * maxt * 16 * sizeof(float);
         hipStream_t s = (hipStream_t)stream;
         static bool attr_done[16] = {false};
-#define VITK_BWD_CASE(T, W)                                                                                                 \
+#define VITK_BWD_CASE(T, W, E)                                                                                                 \
     case T: {                                                                                                               \
         if (!attr_done[T]) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_res_kernel<T, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_res_kernel<T, W, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
             if (e != hipSuccess) { vitk_set_error("attention_bwd: cannot set LDS size %zu: %s", smem, hipGetErrorString(e)); return VITK_ELAUNCH; } \
             attr_done[T] = true;                                                                                            \
         }                                                                                                                   \
-        attn_bwd_res_kernel<T, W><<<B * H, W * 64, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, \
+        attn_bwd_res_kernel<T, W, E><<<B * H, W * 64, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, \
                                                               (bf16_t*)dqkv, N, H, scale);                                  \
     } break;
         switch (maxt) {
-            VITK_BWD_CASE(2, 2) VITK_BWD_CASE(4, 4) VITK_BWD_CASE(6, 6) VITK_BWD_CASE(8, 4) VITK_BWD_CASE(10, 5)
-            VITK_BWD_CASE(12, 6) VITK_BWD_CASE(14, 7)
+            VITK_BWD_CASE(2, 2, 4) VITK_BWD_CASE(4, 4, 4) VITK_BWD_CASE(6, 6, 4) VITK_BWD_CASE(8, 4, 4) VITK_BWD_CASE(10, 5, 4)
+            VITK_BWD_CASE(12, 6, 4) VITK_BWD_CASE(14, 7, 4)
             default: vitk_set_error("attention_bwd: unsupported token count %d", N); return VITK_EINVAL;
         }
 #undef VITK_BWD_CASE
