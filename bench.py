@@ -26,6 +26,7 @@ import torch.distributed as dist
 
 FLOP_PER_IMAGE = {"vit_base_patch16_224": 105.38e9}          # train = 6 x forward MACs, GEMM + attention contractions
 GEMM_FLOP_PER_IMAGE = {"vit_base_patch16_224": 101.09e9}     # the linears/patch/head share (attention products: 4.29e9)
+NT_TRAFFIC_BYTES_PER_LAUNCH = 1.14e9     # 2 x 383.9e6 (FETCH_SIZE) + 372.2e6 (WRITE_SIZE), profiles/r1_pmc_hbm.md
 PEAK_BF16_TFLOPS = 2500.0                                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -159,11 +160,17 @@ def main():
             ach = nt_fl / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else 0.0
             result["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32; all epilogue instantiations: forward linears + data gradients)",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                # HBM-side bytes per launch (average over this kernel family's launches of a step), from two separate
+                # rocprofv3 --pmc passes over this same command (FETCH_SIZE doubled as gfx950 needs, + WRITE_SIZE):
+                # profiles/r1_pmc_hbm.md.  Counters cannot be read from inside the process, so this is the committed
+                # measurement for the default workload and null for anything else.
+                "traffic": NT_TRAFFIC_BYTES_PER_LAUNCH if (args.model == "vit_base_patch16_224" and args.batch == 512) else None,
+                "traffic_unit": "bytes/launch (algorithmic: 8.14e8)",
+                "kernel": "gemm_ntp_kernel / gemm_nt_kernel (bf16 MFMA 16x16x32; all epilogue instantiations: forward linears + data gradients)",
                 "launches": nt_n, "avg_launch_ms": round(nt_ms / max(nt_n, 1), 4),
                 "flop_per_launch_avg": round(nt_fl / max(nt_n, 1) / 1e9, 2),
-                "also": {"kernel": "gemm_tn_kernel (weight gradients)", "achieved": round(tn_fl / (tn_ms * 1e-3) / 1e12, 1) if tn_ms > 0 else 0.0,
+                "also": {"kernel": "gemm_tnb_kernel / gemm_tn_kernel (weight gradients)", "achieved": round(tn_fl / (tn_ms * 1e-3) / 1e12, 1) if tn_ms > 0 else 0.0,
                          "launches": tn_n, "avg_launch_ms": round(tn_ms / max(tn_n, 1), 4)},
                 "gemm_share_of_step": round((nt_ms + tn_ms) / (elapsed * 1e3), 3),
             }
