@@ -123,6 +123,10 @@ int vitk_rowscale(const void* x, const float* rowscale, int rows_per_group, void
 int vitk_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int vitk_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 int vitk_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);
+/* The same for n matrices in ONE launch (the per-step refresh of all transposed weight copies).  desc is a DEVICE array of
+ * n+1 records of five int64: {src address, dst address, rows, cols, first_tile}, first_tile = number of 64x64 tiles of the
+ * records before it; record n only carries first_tile = total_tiles. */
+int vitk_transpose_bf16_batched(const void* desc, int n, int total_tiles, void* stream);
 int vitk_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 
 /* ---- losses on fp32 logits [B,C] with leading dim ld.  loss_rows fp32 [B] per-sample loss, dlogits fp32 [B,C]

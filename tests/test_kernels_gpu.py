@@ -316,6 +316,12 @@ def test_elementwise(device):
     assert torch.equal(ops.transpose_bf16(t.to(device)).cpu(), t.t().contiguous())
     t = _randb((70, 130), g)
     assert torch.equal(ops.transpose_bf16(t.to(device)).cpu(), t.t().contiguous())
+    # all matrices of a list in one launch (ragged shapes, bit-exact)
+    mats = [_randb(sh, g).to(device) for sh in ((768, 2304), (70, 130), (1000, 768), (64, 64), (1, 8))]
+    outs = [torch.empty((m.shape[1], m.shape[0]), dtype=bf16, device=device) for m in mats]
+    ops.transpose_bf16_batched(ops.transpose_plan(list(zip(mats, outs))))
+    for m, o in zip(mats, outs):
+        assert torch.equal(o, m.t().contiguous())
     a, b = _randb((1003,), g), _randb((1003,), g)
     assert torch.equal(ops.add_bf16(a.to(device), b.to(device)).cpu(), (a.float() + b.float()).to(bf16))
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vitk_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
     "vitk_cast_bf16_to_f32": (_i, [_p, _p, _i64, _p]),
     "vitk_transpose_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "vitk_transpose_bf16_batched": (_i, [_p, _i, _i, _p]),
     "vitk_add_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "vitk_xent_label_fwd_bwd": (_i, [_p, _i, _p, _f, _p, _p, _i, _f, _i, _i, _p]),
     "vitk_xent_soft_fwd_bwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _f, _i, _i, _p]),

@@ -228,6 +228,33 @@ __global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __
     }
 }
 
+// The same for a list of matrices in one launch.  desc[i] = {src address, dst address, rows, cols, first tile}: five 64-bit
+// words per matrix, first tile = number of 64x64 tiles of the matrices before it; desc[n].first tile = total tiles.
+__global__ void transpose_bf16_batched_kernel(const long long* __restrict__ desc, int n) {
+    __shared__ bf16_t tile[64][66];
+    int lo = 0, hi = n - 1;                 // last matrix whose first tile <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid * 5 + 4] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(desc[lo * 5]);
+    bf16_t* dst = reinterpret_cast<bf16_t*>(desc[lo * 5 + 1]);
+    const int rows = (int)desc[lo * 5 + 2], cols = (int)desc[lo * 5 + 3];
+    const int t = (int)(blockIdx.x - desc[lo * 5 + 4]);
+    const int tiles_c = (cols + 63) / 64;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int gr = r0 + r, gc = c0 + tx;
+        tile[r][tx] = (gr < rows && gc < cols) ? src[(size_t)gr * cols + gc] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {
+        const int gc = c0 + c, gr = r0 + tx;
+        if (gc < cols && gr < rows) dst[(size_t)gc * rows + gr] = tile[tx][c];
+    }
+}
+
 extern "C" {
 
 int vitk_im2col_patches(const float* img, void* patches, int B, int C, int H, int W, int p, void* stream) {
@@ -328,6 +355,13 @@ int vitk_transpose_bf16(const void* src, void* dst, int rows, int cols, void* st
     dim3 grid((cols + 63) / 64, (rows + 63) / 64);
     transpose_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)src, (bf16_t*)dst, rows, cols);
     return vitk_check_launch("transpose_bf16");
+}
+
+int vitk_transpose_bf16_batched(const void* desc, int n, int total_tiles, void* stream) {
+    VITK_REQUIRE(desc && n > 0 && total_tiles > 0, "transpose_bf16_batched: bad arguments");
+    VITK_REQUIRE(vitk_aligned(desc, 8), "transpose_bf16_batched: descriptor table must be 8-byte aligned");
+    transpose_bf16_batched_kernel<<<total_tiles, 256, 0, (hipStream_t)stream>>>((const long long*)desc, n);
+    return vitk_check_launch("transpose_bf16_batched");
 }
 
 int vitk_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream) {

@@ -243,6 +243,25 @@ def transpose_bf16(src, dst=None):
     return dst
 
 
+def transpose_plan(pairs):
+    """Device descriptor table for transpose_bf16_batched: pairs = [(src [r,c] bf16, dst [c,r] bf16), ...]."""
+    rec, first = [], 0
+    for src, dst in pairs:
+        _chk(src, bf16, "src"); _chk(dst, bf16, "dst")
+        r, c = src.shape
+        if tuple(dst.shape) != (c, r) or not src.is_contiguous() or not dst.is_contiguous():
+            raise _lib.VitkError("transpose_plan: dst must be the contiguous [cols, rows] partner of a contiguous src")
+        rec.append([src.data_ptr(), dst.data_ptr(), r, c, first])
+        first += ((r + 63) // 64) * ((c + 63) // 64)
+    rec.append([0, 0, 0, 0, first])
+    return torch.tensor(rec, dtype=torch.int64, device=pairs[0][0].device), len(pairs), first
+
+
+def transpose_bf16_batched(plan):
+    desc, n, total = plan
+    check(_lib.load().vitk_transpose_bf16_batched(_ptr(desc), n, total, _stream()), "transpose_bf16_batched")
+
+
 def add_bf16(a, b, out=None):
     _chk(a, bf16, "a"); _chk(b, bf16, "b")
     if out is None:

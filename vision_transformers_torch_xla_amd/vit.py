@@ -305,14 +305,18 @@ class VisionTransformer(nn.Module):
 
     def _refresh_transposes(self):
         """[in, out] bf16 copies of the linears: the data-gradient GEMM dX = dY @ W runs as gemm_nt(dY, W^T)."""
-        for n, src in self._wb.items():
-            if n == "patch_embed.proj.weight":      # the image needs no gradient
-                continue
-            dst = self._wt.get(n)
-            if dst is None or dst.device != src.device:
+        key = (self._flat["b"].data_ptr(), str(self._flat["b"].device))
+        if getattr(self, "_wt_plan_key", None) != key:
+            pairs = []
+            for n, src in self._wb.items():
+                if n == "patch_embed.proj.weight":      # the image needs no gradient
+                    continue
                 dst = torch.empty((src.shape[1], src.shape[0]), dtype=bf16, device=src.device)
                 self._wt[n] = dst
-            ops.transpose_bf16(src, dst)
+                pairs.append((src, dst))
+            self._wt_plan = ops.transpose_plan(pairs)   # one launch for all of them
+            self._wt_plan_key = key
+        ops.transpose_bf16_batched(self._wt_plan)
 
     def _views_ok(self):
         p0, off0 = self._plist[0], self._offs[self._pnames[0]]
