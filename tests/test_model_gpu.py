@@ -214,6 +214,24 @@ def test_forward_backward_end_to_end(device, name, pool, dpr, emulate):
     assert worst[0] <= 3 * E2E_GRAD_TOL, worst
 
 
+# Real widths of the benchmark configurations, one or two blocks deep: ViT-B at 44 images (8 668 token rows: the persistent NT
+# GEMM, the large-tile weight-gradient GEMM with a ragged last row step, 12-head resident attention) and ViT-L (D = 1024).
+@pytest.mark.parametrize("name,B,depth", [("vit_base_patch16_224", 44, 1), ("vit_large_patch16_224", 6, 2)])
+def test_real_width_models(device, name, B, depth):
+    ref, m = _pair(name, device, depth=depth, global_pool="avg", dpr=0.1)
+    x, y = _batch(B, 224, 40, 13)
+    ref.train()
+    scales = ref.make_drop_scales(B, generator=torch.Generator().manual_seed(5))
+    out, loss_ref, got, loss = _train_step_grads(ref, m, device, x, y, scales, emulate=True)
+    assert rel_l2(got, out) <= E2E_TOL
+    assert abs(loss.item() - loss_ref.item()) <= E2E_TOL * abs(loss_ref.item())
+    gv, rv = _gradvec(m, ref)
+    eall = rel_l2(gv, rv)
+    cos = torch.nn.functional.cosine_similarity(gv.double(), rv.double(), dim=0).item()
+    print(f"{name} B={B} depth={depth}: logits rel {rel_l2(got, out):.2e}, whole-gradient rel {eall:.2e}, cosine {cos:.6f}")
+    assert eall <= E2E_GRAD_TOL and cos >= 0.9995
+
+
 def test_grad_accumulation_and_zero_grad(device):
     ref, m = _pair("vit_tiny_patch16_224", device, depth=2)
     x, y = _batch(4, 224, 40, 11)
