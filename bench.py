@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("VITK_BENCH_WATCHDOG"):        # debugging aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VITK_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -87,10 +90,22 @@ def main():
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernels are the only implementation of the hot path")
+    # Rehearsal switches for a box with fewer GPUs than ranks (never set by the driver): VITK_SHARE_GPU=1 puts every rank
+    # on cuda:0, VITK_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+    if os.environ.get("VITK_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("VITK_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
+    force_dist = os.environ.get("VITK_BENCH_FORCE_DIST") == "1"     # rehearsal: RCCL collectives in a one-rank group
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+    if world > 1 or force_dist:
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
+        else:
+            dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
 
     from vision_transformers_torch_xla_amd import engine, ops, optim_factory, utils
     from vision_transformers_torch_xla_amd.dp import DistributedDataParallel
@@ -99,7 +114,9 @@ def main():
 
     torch.manual_seed(0)                                       # identical init on every rank (plus rank-0 broadcast)
     core = create_model(args.model, pretrained=False, num_classes=1000, global_pool="avg", drop_path_rate=0.1).to(device)
-    model = DistributedDataParallel(core, device_ids=[local]) if world > 1 else core
+    bucket = int(os.environ.get("VITK_DP_BUCKET_MB", "32")) << 20
+    model = (DistributedDataParallel(core, device_ids=[local], bucket_bytes=bucket, single_rank_collectives=force_dist)
+             if (world > 1 or force_dist) else core)
 
     class OptArgs:
         opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 4e-3, 0.05, 1e-8, None
@@ -136,7 +153,7 @@ def main():
     if want_roof:
         ops.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
@@ -185,7 +202,7 @@ def main():
                 log(f"[bench] cpu baseline failed: {e!r}")
                 result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

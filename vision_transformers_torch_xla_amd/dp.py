@@ -15,18 +15,25 @@ leaving >= 10 buckets to overlap.
 from __future__ import annotations
 
 import contextlib
+import os
+import sys
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
 
+_DEBUG = os.environ.get("VITK_DP_DEBUG") == "1"
+
+
 class GradReducer:
-    def __init__(self, flat_grad_getter, process_group=None, bucket_bytes=32 << 20):
+    def __init__(self, flat_grad_getter, process_group=None, bucket_bytes=32 << 20, single_rank_collectives=False):
         self._get = flat_grad_getter
         self.pg = process_group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # a one-rank group normally skips communication; a rehearsal on a one-GPU box can ask for the collectives anyway
+        self._skip = self.world <= 1 and not (single_rank_collectives and dist.is_initialized())
         self.enabled = True
         self._done = 0
         self._works = []
@@ -42,7 +49,7 @@ class GradReducer:
     def ready(self, upto: int, final: bool):
         """Backward reports that gradients in [0, upto) are final.  Reduce [done, upto) once it is a bucket's worth
         (or at the end)."""
-        if not self.enabled or self.world <= 1:
+        if not self.enabled or self._skip:
             if final:
                 self._done = 0
             return
@@ -57,6 +64,11 @@ class GradReducer:
             return
         g = self._get()[a:b]
         self.launched.append((a, b))
+        if _DEBUG:
+            print(f"[dp] rank {dist.get_rank(self.pg)} all-reduce [{a}, {b})", file=sys.stderr, flush=True)
+        # RCCL averages inside the collective; gloo (CPU rehearsal, or several ranks sharing one GPU) has no AVG:
+        # pre-scale, then SUM
+        native_avg = dist.get_backend(self.pg) == "nccl"
         if g.is_cuda:
             cur = torch.cuda.current_stream(g.device)
             side = self._side_stream(g.device)
@@ -64,12 +76,20 @@ class GradReducer:
             ev.record(cur)                      # the slice is complete once everything queued so far has run
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg)     # RCCL averages in the collective itself
+                if native_avg:
+                    dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg)
+                else:
+                    # gloo rehearsal with GPU tensors: stage through the host on this side stream and reduce there.
+                    # (ProcessGroupGloo's own device path takes a fresh pool stream per call and stalls after a few
+                    # dozen calls when two ranks share a device.)
+                    host = g.to("cpu")                   # waits for the slice (side stream is ordered after `ev`)
+                    host.mul_(1.0 / self.world)
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg)
+                    g.copy_(host)
                 done = torch.cuda.Event()
                 done.record(side)
             self._events.append(done)
         else:
-            # gloo (CPU rehearsal of the same bucketing logic) has no AVG: pre-scale, then SUM
             g.mul_(1.0 / self.world)
             self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -91,16 +111,16 @@ class DistributedDataParallel(nn.Module):
     (main.py:855-858), for the flat-buffer VisionTransformer (optionally inside StudentWithDistillation)."""
 
     def __init__(self, module, device_ids=None, find_unused_parameters=False, process_group=None, bucket_bytes=32 << 20,
-                 broadcast_parameters=True):
+                 broadcast_parameters=True, single_rank_collectives=False):
         super().__init__()
         self.module = module
         core = module.student if hasattr(module, "student") else module
         if not hasattr(core, "_flat"):
             raise RuntimeError("DistributedDataParallel: expected a vision_transformers_torch_xla_amd VisionTransformer")
         self._core = core
-        self.reducer = GradReducer(lambda: core._flat["g"], process_group, bucket_bytes)
+        self.reducer = GradReducer(lambda: core._flat["g"], process_group, bucket_bytes, single_rank_collectives)
         core._grad_ready_hook = self.reducer.ready
-        if broadcast_parameters and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        if broadcast_parameters and dist.is_initialized() and not self.reducer._skip:
             if not core._views_ok():
                 core._flatten()
             dist.broadcast(core._flat["p"], src=0, group=process_group)
