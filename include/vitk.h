@@ -92,7 +92,8 @@ int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int l
  * qkv bf16 [B*N, 3*H*64] (columns: [q|k|v] x head x 64, exactly nn.Linear(D,3D)'s output), out bf16 [B*N, H*64],
  * lse fp32 [B,H,N] = log sum exp of the scaled scores (saved for backward). */
 int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream);
-/* dqkv bf16 [B*N, 3*H*64] from dout, qkv, out, lse.  workspace (fp32 dq accumulator) only needed when N > 224. */
+/* dqkv bf16 [B*N, 3*H*64] from dout, qkv, out, lse; N <= 608.  No workspace is needed (the size query returns 0 and the
+ * workspace arguments are ignored); both stay in the signature so that callers sized for a workspace keep working. */
 size_t vitk_attention_bwd_workspace(int B, int N, int H);
 int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                        int B, int N, int H, float scale, void* workspace, size_t workspace_bytes, void* stream);

@@ -50,7 +50,8 @@ def test_validation_rejects_before_launch():
     assert lib.vitk_gemm_tn(p16, 8, p16, 8, p16, 8, 64, 8, 8, None, 0, p16, 16, None) == -28     # workspace too small
     assert lib.vitk_attention_fwd(p16, p16, p16, 1, 700, 1, 0.125, None) == -22                   # N > 608
     assert lib.vitk_gemm_tn_workspace(100864, 3072, 768) > 0 and lib.vitk_layernorm_bwd_workspace(100, 768) > 0
-    assert lib.vitk_attention_bwd_workspace(2, 197, 12) == 0 and lib.vitk_attention_bwd_workspace(2, 577, 12) == 2 * 577 * 768 * 4
+    assert lib.vitk_attention_bwd_workspace(2, 197, 12) == 0 and lib.vitk_attention_bwd_workspace(2, 577, 12) == 0
+    assert lib.vitk_attention_bwd(p16, p16, p16, p16, p16, 1, 700, 1, 0.125, None, 0, None) == -22       # N > 608
 
 
 def test_ops_reject_cpu_tensors():

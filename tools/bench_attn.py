@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the fused attention kernels on the ViT-B/16 shape (B=512, N=197, H=12): time and HBM rate.
-usage: python tools/bench_attn.py [reps]"""
+usage: python tools/bench_attn.py [reps] [B] [N]"""
 import sys
 from pathlib import Path
 
@@ -25,7 +25,9 @@ def timeit(fn, reps):
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-    B, N, H = 512, 197, 12
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    N = int(sys.argv[3]) if len(sys.argv) > 3 else 197
+    H = 12
     D = 64 * H
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)

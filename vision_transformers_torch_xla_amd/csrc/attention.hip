@@ -6,8 +6,8 @@
 //   forward : S^T = K Q^T (key rows, query on the lane)  ->  softmax along registers + 2 shuffles
 //             O^T = V^T P^T with the S^T accumulators reused in place as the B operand (bf16-packed),
 //             V^T fragments by the transposing LDS read ds_read_b64_tr_b16.
-//   backward: S = Q K^T and dP = dO V^T with the key on the lane; P and dS (bf16-packed accumulators) feed
-//             dV^T += dO^T P and dK^T += Q^T dS directly; only dS crosses LDS once for dQ^T = K^T dS^T.
+//   backward: two phases over one LDS image (Q, dO first; then K, V): key-owner waves form dK, dV, query-owner waves
+//             recompute the scores and form dQ; nothing crosses between waves (see attn_bwd_res_kernel).
 // qkv is nn.Linear(D,3D)'s output [B*N, 3*H*64]; column = which*H*64 + head*64 + d.
 #include "common.h"
 
@@ -162,232 +162,16 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
 }
 
 // ----------------------------------------------------------------------------------------------- backward
-#define KB_MAX 224    // keys per workgroup (14 tiles of 16)
-#define KB_TILES 14
-#define QSTEP 32
-
-// one workgroup = (batch*head, key block).  dq_acc != nullptr: several key blocks add their dQ into fp32.
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                        bf16_t* __restrict__ dqkv, float* __restrict__ dq_acc, int N, int H,
-                                                        float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(attn_smem);            // [224][64] swizzled
-    bf16_t* Vs = Ks + KB_MAX * HD;                                 // [224][64] swizzled
-    bf16_t* Qs = Vs + KB_MAX * HD;                                 // [32][64]  swizzled
-    bf16_t* dOs = Qs + QSTEP * HD;                                 // [32][64]  swizzled
-    bf16_t* dSs = dOs + QSTEP * HD;                                // [224][32] (key rows, 32 queries)
-    float* lse_s = reinterpret_cast<float*>(dSs + KB_MAX * QSTEP); // [32]
-    float* dl_s = lse_s + QSTEP;                                   // [32]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 15, lg = lane >> 4, lq = lr >> 2, lp = lr & 3;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int D = H * HD, ld = 3 * D;
-    const int key0 = blockIdx.y * KB_MAX;
-    int nkeys = N - key0; nkeys = nkeys < KB_MAX ? nkeys : KB_MAX;
-    const int nkt = (nkeys + 15) / 16;            // real key tiles in this block
-    const int nk32 = (nkeys + 31) / 32;           // 32-key contraction steps for dQ
-    const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
-
-    for (int ci = tid; ci < KB_MAX * 8; ci += 256) {
-        const int key = ci >> 3, ch = ci & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < nkeys) {
-            const bf16_t* rowp = base + (size_t)(key0 + key) * ld + ch * 8;
-            kv = *reinterpret_cast<const uint4*>(rowp + D);
-            vv = *reinterpret_cast<const uint4*>(rowp + 2 * D);
-        }
-        const int off = key * HD + ((ch ^ (key & 7)) << 3);
-        *reinterpret_cast<uint4*>(&Ks[off]) = kv;
-        *reinterpret_cast<uint4*>(&Vs[off]) = vv;
-    }
-
-    f32x4 dv[4][4], dk[4][4];   // [owned key tile][d tile]: D[d = 4lg+r][key = lr]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { dv[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    const int nsteps = (N + QSTEP - 1) / QSTEP;
-    const int srow = tid >> 3, sch = tid & 7;     // staging: 32 rows x 8 chunks
-    for (int st = 0; st < nsteps; ++st) {
-        const int q0 = st * QSTEP;
-        {   // stage Q, dO (swizzled) and delta = rowsum(dO * O), lse
-            const int q = q0 + srow;
-            uint4 qv = make_uint4(0, 0, 0, 0), dov = make_uint4(0, 0, 0, 0);
-            float part = 0.f;
-            if (q < N) {
-                qv = *reinterpret_cast<const uint4*>(base + (size_t)q * ld + sch * 8);
-                const size_t oo = ((size_t)b * N + q) * D + h * HD + sch * 8;
-                dov = *reinterpret_cast<const uint4*>(dout + oo);
-                float a[8], c[8];
-                load8(dout + oo, a);
-                load8(out + oo, c);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) part += a[j] * c[j];
-            }
-            part += __shfl_xor(part, 1, 64);
-            part += __shfl_xor(part, 2, 64);
-            part += __shfl_xor(part, 4, 64);
-            const int off = srow * HD + ((sch ^ (srow & 7)) << 3);
-            *reinterpret_cast<uint4*>(&Qs[off]) = qv;
-            *reinterpret_cast<uint4*>(&dOs[off]) = dov;
-            if (sch == 0) {
-                dl_s[srow] = part;
-                lse_s[srow] = (q < N) ? lse[((size_t)b * H + h) * N + q] : 0.f;
-            }
-        }
-        __syncthreads();
-
-        // per-step fragments shared by all of the wave's key tiles
-        bf16x8 qf[2][2], dof[2][2], qtr[4], dotr[4];
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int row = qi * 16 + lr;
-                const int off = row * HD + (((ks * 4 + lg) ^ (row & 7)) << 3);
-                qf[qi][ks] = *reinterpret_cast<const bf16x8*>(&Qs[off]);
-                dof[qi][ks] = *reinterpret_cast<const bf16x8*>(&dOs[off]);
-            }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int rlo = 4 * lg + lq, rhi = 16 + 4 * lg + lq, col = dt * 16 + 4 * lp;
-            qtr[dt] = tr_frag2(&Qs[swz(rlo, col)], &Qs[swz(rhi, col)]);
-            dotr[dt] = tr_frag2(&dOs[swz(rlo, col)], &dOs[swz(rhi, col)]);
-        }
-        float lrow[2][4], drow[2][4];
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                lrow[qi][r] = lse_s[qi * 16 + 4 * lg + r];
-                drow[qi][r] = dl_s[qi * 16 + 4 * lg + r];
-            }
-
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            const int kt = wave + 4 * ti;
-            if (kt < nkt) {
-                const int key = kt * 16 + lr;
-                bf16x8 kf[2], vf[2];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int off = key * HD + (((ks * 4 + lg) ^ (key & 7)) << 3);
-                    kf[ks] = *reinterpret_cast<const bf16x8*>(&Ks[off]);
-                    vf[ks] = *reinterpret_cast<const bf16x8*>(&Vs[off]);
-                }
-                f32x4 pt[2], ds[2];
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi) {
-                    f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qi][ks], kf[ks], sacc, 0, 0, 0);
-                        dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[qi][ks], vf[ks], dpacc, 0, 0, 0);
-                    }
-                    // sacc[r] = S[q = 16qi + 4lg + r][key = lr]
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __expf(sacc[r] * scale - lrow[qi][r]);
-                        pt[qi][r] = p;
-                        ds[qi][r] = p * (dpacc[r] - drow[qi][r]) * scale;
-                    }
-                }
-                const bf16x8 pa = pack8(pt[0], pt[1]);     // k-slot (lg, j): q = 4lg+j (j<4) | 16+4lg+j-4
-                const bf16x8 dsa = pack8(ds[0], ds[1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    dv[ti][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr[dt], pa, dv[ti][dt], 0, 0, 0);
-                    dk[ti][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsa, dk[ti][dt], 0, 0, 0);
-                }
-                // dS^T image [key][32 q]: lane writes q = 16qi + 4lg .. +3 for its key
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi) {
-                    uint2 w;
-                    w.x = pack2bf(ds[qi][0], ds[qi][1]);
-                    w.y = pack2bf(ds[qi][2], ds[qi][3]);
-                    *reinterpret_cast<uint2*>(&dSs[key * QSTEP + qi * 16 + 4 * lg]) = w;
-                }
-            } else if (kt < 2 * nk32) {
-                // padded key tile inside the last 32-key contraction step: its dS rows must read as zero
-                const int key = kt * 16 + lr;
-#pragma unroll
-                for (int qi = 0; qi < 2; ++qi)
-                    *reinterpret_cast<uint2*>(&dSs[key * QSTEP + qi * 16 + 4 * lg]) = make_uint2(0, 0);
-            }
-        }
-        __syncthreads();
-
-        // dQ^T[d][q] = sum_key K[key][d] * dS[q][key] : wave -> (qi, two d tiles)
-        {
-            const int qi = wave >> 1;
-            f32x4 dq[2];
-            dq[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            dq[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int kk = 0; kk < nk32; ++kk) {
-                const int rlo = kk * 32 + 8 * lg + lq, rhi = rlo + 4;
-                const bf16x8 dst = tr_frag2(&dSs[rlo * QSTEP + qi * 16 + 4 * lp], &dSs[rhi * QSTEP + qi * 16 + 4 * lp]);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int col = (2 * (wave & 1) + e) * 16 + 4 * lp;
-                    const bf16x8 ktr = tr_frag2(&Ks[swz(rlo, col)], &Ks[swz(rhi, col)]);
-                    dq[e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dst, dq[e], 0, 0, 0);
-                }
-            }
-            // dq[e][r] = dQ[q = q0 + 16qi + lr][d = 16*(2*(wave&1)+e) + 4lg + r]
-            const int q = q0 + qi * 16 + lr;
-            if (q < N) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int d = (2 * (wave & 1) + e) * 16 + 4 * lg;
-                    if (dq_acc != nullptr) {
-                        float* ap = dq_acc + ((size_t)b * N + q) * D + h * HD + d;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(ap + r, dq[e][r]);
-                    } else {
-                        uint2 w;
-                        w.x = pack2bf(dq[e][0], dq[e][1]);
-                        w.y = pack2bf(dq[e][2], dq[e][3]);
-                        *reinterpret_cast<uint2*>(dqkv + ((size_t)b * N + q) * ld + h * HD + d) = w;
-                    }
-                }
-            }
-        }
-        // the next step's staging only touches Qs/dOs/lse_s/dl_s, which nobody reads after the barrier above;
-        // its first barrier orders this dQ phase before the next dSs writes.
-    }
-
-    // dK, dV of the owned key tiles: lane holds [key = lr][d = 16dt + 4lg + r]
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-        const int kt = wave + 4 * ti;
-        const int key = kt * 16 + lr;
-        if (kt < nkt && key < nkeys) {
-            bf16_t* rowp = dqkv + ((size_t)b * N + key0 + key) * ld + h * HD + 4 * lg;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 wk, wv;
-                wk.x = pack2bf(dk[ti][dt][0], dk[ti][dt][1]); wk.y = pack2bf(dk[ti][dt][2], dk[ti][dt][3]);
-                wv.x = pack2bf(dv[ti][dt][0], dv[ti][dt][1]); wv.y = pack2bf(dv[ti][dt][2], dv[ti][dt][3]);
-                *reinterpret_cast<uint2*>(rowp + D + dt * 16) = wk;
-                *reinterpret_cast<uint2*>(rowp + 2 * D + dt * 16) = wv;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------- backward, resident variant
-// For heads of at most 224 tokens.  Two barrier-free phases; the scores are recomputed in the second instead of passing dS
+// Two barrier-free phases; the scores are recomputed in the second instead of passing dS
 // between waves:
 //   phase 1, a wave owns key tiles:   S = Q K^T, dP = dO V^T (key on the lane), P = 2^(S c - lse'), dS = P (dP - delta) scale,
 //                                     dV^T += dO^T P, dK^T += Q^T dS   (Q^T, dO^T by transposing reads)
 //   phase 2, a wave owns query tiles: S^T = K Q^T, dP^T = V dO^T (query on the lane), same P and dS, dQ^T += K^T dS^T.
 // What all waves share goes through LDS ([NPAD][64] images, chunk XOR-swizzled by row & 7, filled by DMA): Q and dO in
 // phase 1, K and V in phase 2 - the SAME 56 KB, refilled between the phases - while what only one wave needs (its own K, V
-// rows in phase 1, its own Q, dO rows in phase 2) comes straight from global memory into registers.  58 KB of LDS and 128
-// registers let two workgroups (14 waves) share a CU, so one head's loads and barriers hide under the other's MFMAs.
+// rows in phase 1, its own Q, dO rows in phase 2) comes straight from global memory into registers.  Up to 224 tokens 58 KB
+// of LDS and 128 registers let two workgroups (14 waves) share a CU, so one head's loads and barriers hide under the other's
+// MFMAs; beyond (up to 608 tokens = 157 KB) one 8-wave workgroup owns the CU.
 // The owned key tiles of phase 1 are processed one after the other, each step in two stages that reuse the same registers
 // (b128 fragments of Q, dO for S and dP; then their transposed fragments for dV, dK).
 // Padding: query rows >= N carry lse' = +inf, so P = dS = 0 there; key rows >= N start the S^T accumulators of phase 2 at
@@ -429,16 +213,17 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         }
     };
     fill(false);
-    // delta and lse: item = (query row, 16-byte chunk), 8 neighbouring lanes share a row; NPAD * 8 items are an exact multiple
-    // of the block size.  All loads of a thread are issued before the first is used.
-    {
-        constexpr int ITEMS = NPAD * 8 / (WAVES * 64);
-        static_assert(ITEMS * WAVES * 64 == NPAD * 8, "items must divide evenly");
+    // delta and lse: item = (query row, 16-byte chunk), 8 neighbouring lanes share a row.  Up to 224 tokens NPAD * 8 items are
+    // an exact multiple of the block size and all loads of a thread are issued before the first is used; beyond, a plain loop
+    // (every trip is taken by whole 8-lane groups, so the shuffles stay inside active lanes).
+    constexpr int TOT = NPAD * 8, STR = WAVES * 64;
+    if constexpr (TOT % STR == 0 && TOT / STR <= 4) {
+        constexpr int ITEMS = TOT / STR;
         u32x4_t ra[ITEMS], rc[ITEMS];
         float lv[ITEMS];
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const int it = tid + i * WAVES * 64;
+            const int it = tid + i * STR;
             int q = it >> 3;
             q = q < N ? q : N - 1;
             ra[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(dobase + (size_t)q * D + (it & 7) * 8));
@@ -447,7 +232,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
-            const int it = tid + i * WAVES * 64;
+            const int it = tid + i * STR;
             const int q = it >> 3;
             float part = 0.f;
 #pragma unroll
@@ -461,6 +246,28 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             if ((it & 7) == 0) {
                 dl_s[q] = part;
                 lse_s[q] = q < N ? lv[i] * 1.44269504088896340736f : INFINITY;
+            }
+        }
+    } else {
+#pragma unroll 2
+        for (int it = tid; it < TOT; it += STR) {
+            const int q = it >> 3;
+            const int qc = q < N ? q : N - 1;
+            const u32x4_t ra = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(dobase + (size_t)qc * D + (it & 7) * 8));
+            const u32x4_t rc = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(obase + (size_t)qc * D + (it & 7) * 8));
+            const float lv = lse[((size_t)b * H + h) * N + qc];
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part += __uint_as_float(ra[j] << 16) * __uint_as_float(rc[j] << 16);
+                part += __uint_as_float(ra[j] & 0xffff0000u) * __uint_as_float(rc[j] & 0xffff0000u);
+            }
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if ((it & 7) == 0) {
+                dl_s[q] = part;
+                lse_s[q] = q < N ? lv * 1.44269504088896340736f : INFINITY;
             }
         }
     }
@@ -634,22 +441,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
     }
 }
 
-// dqkv[:, q columns] = bf16(dq_acc)
-__global__ void attn_dq_convert_kernel(const float* __restrict__ dq_acc, bf16_t* __restrict__ dqkv, size_t rows, int D) {
-    const size_t total = rows * (size_t)(D / 4);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = i / (D / 4);
-        const int c = (int)(i % (D / 4)) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(dq_acc + r * D + c);
-        uint2 w;
-        w.x = pack2bf(v.x, v.y);
-        w.y = pack2bf(v.z, v.w);
-        *reinterpret_cast<uint2*>(dqkv + r * 3 * D + c) = w;
-    }
-}
-
-static const size_t kBwdSmem = (size_t)(2 * KB_MAX * HD + 2 * QSTEP * HD + KB_MAX * QSTEP) * sizeof(bf16_t) + 2 * QSTEP * sizeof(float);
-
 extern "C" {
 
 int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream) {
@@ -681,21 +472,21 @@ int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int
 }
 
 size_t vitk_attention_bwd_workspace(int B, int N, int H) {
-    if (B <= 0 || N <= 0 || H <= 0 || N <= KB_MAX) return 0;
-    return (size_t)B * N * H * HD * sizeof(float);
+    (void)B; (void)N; (void)H;
+    return 0;       // the backward keeps everything in LDS and registers
 }
 
 int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N,
                        int H, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
     VITK_REQUIRE(qkv && out && dout && lse && dqkv, "attention_bwd: null pointer");
-    VITK_REQUIRE(B > 0 && N > 0 && H > 0, "attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
+    VITK_REQUIRE(B > 0 && N > 0 && H > 0 && N <= 608, "attention_bwd: need B,H>0 and 0<N<=608 (B=%d N=%d H=%d)", B, N, H);
     VITK_REQUIRE(vitk_aligned(qkv, 16) && vitk_aligned(out, 16) && vitk_aligned(dout, 16) && vitk_aligned(dqkv, 16),
                  "attention_bwd: pointers must be 16-byte aligned");
-    if (N <= KB_MAX) {
-        const int maxt = 2 * ((N + 31) / 32);
-        const size_t smem = (size_t)2 * maxt * 16 * HD * sizeof(bf16_t) + (size_t)2 * maxt * 16 * sizeof(float);
-        hipStream_t s = (hipStream_t)stream;
-        static bool attr_done[16] = {false};
+    const int maxt = 2 * ((N + 31) / 32);
+    const size_t smem = (size_t)2 * maxt * 16 * HD * sizeof(bf16_t) + (size_t)2 * maxt * 16 * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_done[40] = {false};
 #define VITK_BWD_CASE(T, W, E)                                                                                                 \
     case T: {                                                                                                               \
         if (!attr_done[T]) {                                                                                                \
@@ -706,40 +497,16 @@ int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const
         attn_bwd_res_kernel<T, W, E><<<B * H, W * 64, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, \
                                                               (bf16_t*)dqkv, N, H, scale);                                  \
     } break;
-        switch (maxt) {
-            VITK_BWD_CASE(2, 2, 4) VITK_BWD_CASE(4, 4, 4) VITK_BWD_CASE(6, 6, 4) VITK_BWD_CASE(8, 4, 4) VITK_BWD_CASE(10, 5, 4)
-            VITK_BWD_CASE(12, 6, 4) VITK_BWD_CASE(14, 7, 4)
-            default: vitk_set_error("attention_bwd: unsupported token count %d", N); return VITK_EINVAL;
-        }
+    switch (maxt) {
+        VITK_BWD_CASE(2, 2, 4) VITK_BWD_CASE(4, 4, 4) VITK_BWD_CASE(6, 6, 4) VITK_BWD_CASE(8, 4, 4) VITK_BWD_CASE(10, 5, 4)
+        VITK_BWD_CASE(12, 6, 4) VITK_BWD_CASE(14, 7, 4)
+        VITK_BWD_CASE(16, 8, 2) VITK_BWD_CASE(18, 8, 2) VITK_BWD_CASE(20, 8, 2) VITK_BWD_CASE(22, 8, 2) VITK_BWD_CASE(24, 8, 2)
+        VITK_BWD_CASE(26, 8, 2) VITK_BWD_CASE(28, 8, 2) VITK_BWD_CASE(30, 8, 2) VITK_BWD_CASE(32, 8, 2) VITK_BWD_CASE(34, 8, 2)
+        VITK_BWD_CASE(36, 8, 2) VITK_BWD_CASE(38, 8, 2)
+        default: vitk_set_error("attention_bwd: unsupported token count %d", N); return VITK_EINVAL;
+    }
 #undef VITK_BWD_CASE
-        return vitk_check_launch("attention_bwd");
-    }
-    const int nkb = (N + KB_MAX - 1) / KB_MAX;
-    const size_t need = vitk_attention_bwd_workspace(B, N, H);
-    float* dq_acc = nullptr;
-    hipStream_t s = (hipStream_t)stream;
-    if (nkb > 1) {
-        if (!workspace || workspace_bytes < need) {
-            vitk_set_error("attention_bwd: workspace %zu < %zu", workspace_bytes, need);
-            return VITK_ENOSPC;
-        }
-        VITK_REQUIRE(vitk_aligned(workspace, 16), "attention_bwd: workspace must be 16-byte aligned");
-        dq_acc = (float*)workspace;
-        hipError_t me = hipMemsetAsync(dq_acc, 0, need, s);
-        if (me != hipSuccess) { vitk_set_error("attention_bwd: memset failed: %s", hipGetErrorString(me)); return VITK_ELAUNCH; }
-    }
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdSmem);
-    if (e != hipSuccess) { vitk_set_error("attention_bwd: cannot set LDS size %zu: %s", kBwdSmem, hipGetErrorString(e)); return VITK_ELAUNCH; }
-    attn_bwd_kernel<<<dim3(B * H, nkb), 256, kBwdSmem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
-                                                           (bf16_t*)dqkv, dq_acc, N, H, scale);
-    int rc = vitk_check_launch("attention_bwd");
-    if (rc) return rc;
-    if (nkb > 1) {
-        const size_t rows = (size_t)B * N;
-        attn_dq_convert_kernel<<<2048, 256, 0, s>>>(dq_acc, (bf16_t*)dqkv, rows, H * HD);
-        rc = vitk_check_launch("attention_bwd_convert");
-    }
-    return rc;
+    return vitk_check_launch("attention_bwd");
 }
 
 }  // extern "C"
