@@ -130,6 +130,17 @@ int vitk_transpose_bf16(const void* src, void* dst, int rows, int cols, void* st
 int vitk_transpose_bf16_batched(const void* desc, int n, int total_tiles, void* stream);
 int vitk_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 
+/* ---- mixup / cutmix in 'batch' mode on the device, in place on the fp32 NCHW batch x [B, per_sample]; sample b is paired
+ * with sample B-1-b (x.flip(0)); B must be even.  Replaces timm.data.Mixup.__call__ as the reference applies it before
+ * every training step (main.py:622-629, engine.py:132-133, 259-260).
+ * mixup : x = x*lam + x.flip(0)*(1-lam), both products rounded before the sum (the reference's mul_ / add_ order). */
+int vitk_mixup_batch(float* x, int B, int64_t per_sample, float lam, float one_minus_lam, void* stream);
+/* cutmix: x[:, :, yl:yh, xl:xh] = x.flip(0)[:, :, yl:yh, xl:xh] (the two samples of a pair swap the box) */
+int vitk_cutmix_batch(float* x, int B, int C, int H, int W, int yl, int yh, int xl, int xh, void* stream);
+/* soft targets fp32 [B,C]: one_hot(target, on, off)*lam + one_hot(target.flip(0), on, off)*(1-lam) (timm mixup_target) */
+int vitk_mixup_targets(const int64_t* target, float* out, int ldo, int B, int C, float lam, float one_minus_lam,
+                       float on_value, float off_value, void* stream);
+
 /* ---- losses on fp32 logits [B,C] with leading dim ld.  loss_rows fp32 [B] per-sample loss, dlogits fp32 [B,C]
  * already scaled by grad_scale (= upstream grad / B for 'mean').
  * Hard labels with label smoothing eps (eps=0: nn.CrossEntropyLoss; eps>0: timm LabelSmoothingCrossEntropy,

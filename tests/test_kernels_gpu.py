@@ -70,7 +70,8 @@ def test_layernorm_fwd_bwd(device, M, D):
 
 
 # ----------------------------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (591, 192, 192), (130, 1000, 768), (1000, 2304, 768), (77, 64, 1000), (128, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (591, 192, 192), (130, 1000, 768), (1000, 2304, 768), (77, 64, 1000), (128, 768, 3072),
+                                   (3000, 200, 3072), (70000, 136, 128)])
 def test_gemm_nt_plain_bias(device, M, N, K):
     from vision_transformers_torch_xla_amd import _lib
     ops = _ops()
@@ -99,7 +100,8 @@ def test_gemm_nt_asymmetric_identity(device):
     assert torch.equal(c.cpu(), b.t().contiguous())
 
 
-@pytest.mark.parametrize("M,N,K", [(394, 768, 768), (200, 192, 192)])
+# the last three take the persistent large-tile kernels (M >= 512, K a multiple of 64): full tiles, ragged M and N
+@pytest.mark.parametrize("M,N,K", [(394, 768, 768), (200, 192, 192), (1024, 768, 768), (1182, 392, 256), (2 * 591, 3072, 128)])
 def test_gemm_nt_epilogues(device, M, N, K):
     from vision_transformers_torch_xla_amd import _lib
     ops = _ops()
@@ -117,6 +119,7 @@ def test_gemm_nt_epilogues(device, M, N, K):
     rpg = M // 2
     res = _randb((M, N), g)
     sc = torch.tensor([0.0, 1.0 / 0.9])
+    assert rpg * 2 == M
     ref = res.float() + sc.repeat_interleave(rpg).unsqueeze(1) * acc
     c = ops.gemm_nt(a.to(device), b.to(device), epilogue=_lib.EPI_BIAS_RES, bias=bias.to(device), res=res.to(device),
                     rowscale=sc.to(device), rows_per_group=rpg)

@@ -255,6 +255,59 @@ __global__ void transpose_bf16_batched_kernel(const long long* __restrict__ desc
     }
 }
 
+// ---------------------------------------------------------------------------------------- mixup / cutmix (batch mode)
+// timm.data.Mixup in 'batch' mode, applied by the reference before every training step (main.py:622-629,
+// engine.py:132-133, 259-260).  Sample b is paired with sample B-1-b (x.flip(0)).
+//   mixup : x = x.mul_(lam).add_(x.flip(0).mul_(1-lam))  -> both products are rounded before the sum: floating-point
+//           contraction is switched off in these kernels (hipcc would otherwise fuse product and sum into one fma, and HIP's
+//           __fmul_rn / __fadd_rn are plain operators that do not prevent it), which makes them bit-exact with that order.
+//   cutmix: x[:, :, yl:yh, xl:xh] = x.flip(0)[:, :, yl:yh, xl:xh]  -> the two samples of a pair swap the box.
+__global__ void mixup_pairs_kernel(float* __restrict__ x, int half, int B, size_t per4, float lam, float oml) {
+#pragma clang fp contract(off)
+    const size_t total = (size_t)half * per4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per4, e = i - b * per4;
+        float4* pa = reinterpret_cast<float4*>(x) + b * per4 + e;
+        float4* pc = reinterpret_cast<float4*>(x) + (size_t)(B - 1 - b) * per4 + e;
+        const float4 a = *pa, c = *pc;
+        float4 na, nc;
+        na.x = a.x * lam + c.x * oml; nc.x = c.x * lam + a.x * oml;
+        na.y = a.y * lam + c.y * oml; nc.y = c.y * lam + a.y * oml;
+        na.z = a.z * lam + c.z * oml; nc.z = c.z * lam + a.z * oml;
+        na.w = a.w * lam + c.w * oml; nc.w = c.w * lam + a.w * oml;
+        *pa = na;
+        *pc = nc;
+    }
+}
+
+// one block per (pair, channel, box row); threads walk the box columns
+__global__ void cutmix_swap_kernel(float* __restrict__ x, int B, int C, int H, int W, int yl, int yh, int xl, int xh) {
+    const int bh = yh - yl;
+    int r = blockIdx.x;
+    const int y = yl + r % bh; r /= bh;
+    const int c = r % C;
+    const int b = r / C;
+    float* pa = x + (((size_t)b * C + c) * H + y) * W;
+    float* pc = x + (((size_t)(B - 1 - b) * C + c) * H + y) * W;
+    for (int xx = xl + threadIdx.x; xx < xh; xx += blockDim.x) {
+        const float a = pa[xx];
+        pa[xx] = pc[xx];
+        pc[xx] = a;
+    }
+}
+
+// timm mixup_target: one_hot(target, on, off) * lam + one_hot(target.flip(0), on, off) * (1 - lam), products rounded first
+__global__ void mixup_targets_kernel(const int64_t* __restrict__ target, float* __restrict__ out, int ldo, int B, int C, float lam,
+                                     float oml, float on, float off) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.x;
+    const int64_t t1 = target[b], t2 = target[B - 1 - b];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float v1 = (c == t1) ? on : off, v2 = (c == t2) ? on : off;
+        out[(size_t)b * ldo + c] = v1 * lam + v2 * oml;
+    }
+}
+
 extern "C" {
 
 int vitk_im2col_patches(const float* img, void* patches, int B, int C, int H, int W, int p, void* stream) {
@@ -369,6 +422,34 @@ int vitk_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream
     VITK_REQUIRE(vitk_aligned(a, 16) && vitk_aligned(b, 16) && vitk_aligned(y, 16), "add_bf16: pointers must be 16-byte aligned");
     add_bf16_kernel<<<ew_grid((size_t)(n / 8 + 1)), EW_BLOCK, 0, (hipStream_t)stream>>>((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
     return vitk_check_launch("add_bf16");
+}
+
+int vitk_mixup_batch(float* x, int B, int64_t per_sample, float lam, float one_minus_lam, void* stream) {
+    VITK_REQUIRE(x && B > 0 && per_sample > 0, "mixup_batch: bad arguments");
+    VITK_REQUIRE(B % 2 == 0, "mixup_batch: batch size should be even when using this (B=%d)", B);
+    VITK_REQUIRE(per_sample % 4 == 0 && vitk_aligned(x, 16), "mixup_batch: elements per sample must be a multiple of 4, x 16-byte aligned");
+    const size_t per4 = (size_t)per_sample / 4;
+    mixup_pairs_kernel<<<ew_grid((size_t)(B / 2) * per4), EW_BLOCK, 0, (hipStream_t)stream>>>(x, B / 2, B, per4, lam, one_minus_lam);
+    return vitk_check_launch("mixup_batch");
+}
+
+int vitk_cutmix_batch(float* x, int B, int C, int H, int W, int yl, int yh, int xl, int xh, void* stream) {
+    VITK_REQUIRE(x && B > 0 && C > 0 && H > 0 && W > 0, "cutmix_batch: bad arguments");
+    VITK_REQUIRE(B % 2 == 0, "cutmix_batch: batch size should be even when using this (B=%d)", B);
+    VITK_REQUIRE(0 <= yl && yl <= yh && yh <= H && 0 <= xl && xl <= xh && xh <= W, "cutmix_batch: box [%d,%d)x[%d,%d) outside %dx%d", yl, yh,
+                 xl, xh, H, W);
+    if (yh == yl || xh == xl) return VITK_OK;       // empty box: nothing moves
+    const long long blocks = (long long)(B / 2) * C * (yh - yl);
+    VITK_REQUIRE(blocks <= 0x7fffffffLL, "cutmix_batch: too many rows");
+    cutmix_swap_kernel<<<(unsigned)blocks, 64, 0, (hipStream_t)stream>>>(x, B, C, H, W, yl, yh, xl, xh);
+    return vitk_check_launch("cutmix_batch");
+}
+
+int vitk_mixup_targets(const int64_t* target, float* out, int ldo, int B, int C, float lam, float one_minus_lam, float on_value,
+                       float off_value, void* stream) {
+    VITK_REQUIRE(target && out && B > 0 && C > 0 && ldo >= C, "mixup_targets: bad arguments");
+    mixup_targets_kernel<<<B, 256, 0, (hipStream_t)stream>>>(target, out, ldo, B, C, lam, one_minus_lam, on_value, off_value);
+    return vitk_check_launch("mixup_targets");
 }
 
 }  // extern "C"

@@ -362,3 +362,30 @@ def prof_read(kind=PROF_ALL):
 
 def prof_reset():
     check(_lib.load().vitk_prof_reset(), "prof_reset")
+
+
+# ------------------------------------------------------------------------------------------ mixup / cutmix
+def mixup_batch_(x, lam: float):
+    """in place: x = x*lam + x.flip(0)*(1-lam) on an fp32 [B, ...] batch"""
+    _chk(x, f32, "x")
+    B = x.shape[0]
+    check(_lib.load().vitk_mixup_batch(_ptr(x), B, x.numel() // B, float(lam), float(1. - lam), _stream()), "mixup_batch")
+    return x
+
+
+def cutmix_batch_(x, yl: int, yh: int, xl: int, xh: int):
+    """in place: x[:, :, yl:yh, xl:xh] = x.flip(0)[:, :, yl:yh, xl:xh] on an fp32 [B,C,H,W] batch"""
+    _chk(x, f32, "x")
+    B, Cc, Hh, Ww = x.shape
+    check(_lib.load().vitk_cutmix_batch(_ptr(x), B, Cc, Hh, Ww, int(yl), int(yh), int(xl), int(xh), _stream()), "cutmix_batch")
+    return x
+
+
+def mixup_targets(target, num_classes: int, lam: float, on_value: float, off_value: float):
+    """int64 labels [B] -> soft targets fp32 [B, num_classes] mixed with the flipped batch's"""
+    _chk(target, torch.int64, "target")
+    B = target.shape[0]
+    out = torch.empty((B, num_classes), dtype=f32, device=target.device)
+    check(_lib.load().vitk_mixup_targets(_ptr(target), _ptr(out), num_classes, B, num_classes, float(lam), float(1. - lam),
+                                         float(on_value), float(off_value), _stream()), "mixup_targets")
+    return out

@@ -224,3 +224,158 @@ class ModelEma:
             self.ema._flatten()
         ops.ema_update(self.ema._flat["p"], src._flat["p"], self.decay)
         self.ema._weights_version = None          # bf16 copies are refreshed on the EMA model's next forward
+
+
+# ---------------------------------------------------------------------------------------------- checkpoints
+def save_on_master(*args, **kwargs):
+    if is_main_process():
+        torch.save(*args, **kwargs)
+
+
+def _plain_args(args):
+    """argparse.Namespace -> dict of plain values, so that the checkpoint loads with torch.load(weights_only=True)"""
+    src = vars(args) if hasattr(args, "__dict__") else dict(args or {})
+    ok = (int, float, str, bool, type(None))
+    return {k: (v if isinstance(v, ok) else [x for x in v] if isinstance(v, (list, tuple)) and all(isinstance(x, ok) for x in v) else str(v))
+            for k, v in src.items()}
+
+
+def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
+    """checkpoint-{epoch}.pth under args.output_dir, written by rank 0: {'model', 'optimizer', 'epoch', 'scaler', 'args'
+    [, 'model_ema']} with timm parameter names, then the checkpoint save_ckpt_num * save_ckpt_freq epochs back is removed
+    (utils/__init__.py:686-732).  'args' is stored as a dict of plain values."""
+    from pathlib import Path
+    output_dir = Path(args.output_dir)
+    output_dir.mkdir(parents=True, exist_ok=True)
+    checkpoint_path = output_dir / ("checkpoint-%s.pth" % str(epoch))
+    to_save = {
+        "model": {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
+        "optimizer": optimizer.state_dict(),
+        "epoch": epoch,
+        "scaler": loss_scaler.state_dict() if loss_scaler is not None else None,
+        "args": _plain_args(args),
+    }
+    if model_ema is not None:
+        ema = model_ema.ema if hasattr(model_ema, "ema") else model_ema
+        to_save["model_ema"] = {k: v.detach().cpu() for k, v in ema.state_dict().items()}
+    save_on_master(to_save, checkpoint_path)
+    if is_main_process() and isinstance(epoch, int):
+        to_del = epoch - getattr(args, "save_ckpt_num", 3) * getattr(args, "save_ckpt_freq", 1)
+        old_ckpt = output_dir / ("checkpoint-%s.pth" % to_del)
+        if os.path.exists(old_ckpt):
+            os.remove(old_ckpt)
+
+
+def _load_checkpoint_file(path):
+    """torch.load that executes nothing from the file; argparse.Namespace (what the reference pickles under 'args') is
+    allowed by name.  URLs are refused: there is no network."""
+    import argparse
+    if str(path).startswith("http"):
+        raise RuntimeError("checkpoint URLs cannot be fetched in this build (no network): pass a local file")
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
+    """Resume from args.resume, or with args.auto_resume from the highest-numbered checkpoint-*.pth in args.output_dir:
+    restores the model, and when the file holds them the optimizer state, args.start_epoch = epoch + 1, the EMA weights
+    and the scaler (utils/__init__.py:735-770)."""
+    import glob
+    from pathlib import Path
+    output_dir = Path(args.output_dir)
+    if getattr(args, "auto_resume", False) and len(getattr(args, "resume", "") or "") == 0:
+        latest_ckpt = -1
+        for ckpt in glob.glob(os.path.join(output_dir, "checkpoint-*.pth")):
+            t = ckpt.split("-")[-1].split(".")[0]
+            if t.isdigit():
+                latest_ckpt = max(int(t), latest_ckpt)
+        if latest_ckpt >= 0:
+            args.resume = os.path.join(output_dir, "checkpoint-%d.pth" % latest_ckpt)
+        print("Auto resume checkpoint: %s" % getattr(args, "resume", ""))
+    if getattr(args, "resume", ""):
+        checkpoint = _load_checkpoint_file(args.resume)
+        model_without_ddp.load_state_dict(checkpoint["model"])
+        print("Resume checkpoint %s" % args.resume)
+        if "optimizer" in checkpoint and "epoch" in checkpoint:
+            optimizer.load_state_dict(checkpoint["optimizer"])
+            if not isinstance(checkpoint["epoch"], str):        # 'best' / 'best-ema' cannot be resumed from
+                args.start_epoch = checkpoint["epoch"] + 1
+            else:
+                assert getattr(args, "eval", False), "Does not support resuming with checkpoint-best"
+            if getattr(args, "model_ema", False) and model_ema is not None:
+                ema = model_ema.ema if hasattr(model_ema, "ema") else model_ema
+                ema.load_state_dict(checkpoint["model_ema"] if "model_ema" in checkpoint else checkpoint["model"])
+            if "scaler" in checkpoint and loss_scaler is not None and checkpoint["scaler"] is not None:
+                loss_scaler.load_state_dict(checkpoint["scaler"])
+            print("With optim & sched!")
+
+
+def load_state_dict(model, state_dict, prefix="", ignore_missing="relative_position_index"):
+    """Non-strict load that reports instead of raising: missing / unexpected keys are printed, keys containing one of the
+    '|'-separated ignore_missing patterns are reported separately (utils/__init__.py:550-596).  Returns
+    (missing, unexpected) besides printing."""
+    sd = {k[len(prefix):] if prefix and k.startswith(prefix) else k: v for k, v in state_dict.items()}
+    own = model.state_dict()
+    error_msgs = [f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, the shape in current model is "
+                  f"{tuple(own[k].shape)}." for k, v in sd.items() if k in own and tuple(own[k].shape) != tuple(v.shape)]
+    loadable = {k: v for k, v in sd.items() if k not in own or tuple(own[k].shape) == tuple(v.shape)}
+    res = model.load_state_dict(loadable, strict=False)
+    missing = [k for k in res.missing_keys if not any(p in k for p in ignore_missing.split("|"))]
+    ignored = [k for k in res.missing_keys if k not in missing]
+    if missing:
+        print("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, missing))
+    if res.unexpected_keys:
+        print("Weights from pretrained model not used in {}: {}".format(model.__class__.__name__, res.unexpected_keys))
+    if ignored:
+        print("Ignored weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, ignored))
+    if error_msgs:
+        print("\n".join(error_msgs))
+    return missing, list(res.unexpected_keys)
+
+
+def resample_abs_pos_embed(posemb, new_size, old_size=None, num_prefix_tokens=1, interpolation="bicubic", antialias=True):
+    """Learned absolute position table [1, prefix + gh*gw, D] -> [1, prefix + new_h*new_w, D]: the grid part is resampled
+    (bicubic, antialiased) in fp32, prefix tokens are carried over (timm resample_abs_pos_embed, the step
+    checkpoint_filter_fn applies at models/vision_transformer.py:1441-1451; needed for a 224 -> 384 px fine-tune)."""
+    import torch.nn.functional as F
+    num_pos_tokens = posemb.shape[1]
+    num_new_tokens = new_size[0] * new_size[1] + num_prefix_tokens
+    if num_new_tokens == num_pos_tokens and new_size[0] == new_size[1]:
+        return posemb
+    if old_size is None:
+        hw = int(math.sqrt(num_pos_tokens - num_prefix_tokens))
+        old_size = hw, hw
+    prefix, grid = (posemb[:, :num_prefix_tokens], posemb[:, num_prefix_tokens:]) if num_prefix_tokens else (None, posemb)
+    embed_dim = grid.shape[-1]
+    orig_dtype = grid.dtype
+    grid = grid.float().reshape(1, old_size[0], old_size[1], -1).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=new_size, mode=interpolation, antialias=antialias)
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, embed_dim).to(orig_dtype)
+    return torch.cat([prefix, grid], dim=1) if prefix is not None else grid
+
+
+def load_finetune_checkpoint(model, path, model_key="model|module", model_prefix=""):
+    """--finetune as main.py:653-674 does it (pick the state dict by model_key, drop a head of another size, non-strict
+    load) plus the position-table resample the reference leaves out, so that a 224 px checkpoint initialises a 384 px
+    model."""
+    checkpoint = _load_checkpoint_file(path)
+    print("Load ckpt from %s" % path)
+    checkpoint_model = None
+    for key in model_key.split("|"):
+        if key in checkpoint:
+            checkpoint_model = checkpoint[key]
+            print("Load state_dict by model_key = %s" % key)
+            break
+    if checkpoint_model is None:
+        checkpoint_model = checkpoint
+    checkpoint_model = dict(checkpoint_model)
+    state_dict = model.state_dict()
+    for k in ["head.weight", "head.bias", "head_dist.weight", "head_dist.bias"]:
+        if k in checkpoint_model and k in state_dict and checkpoint_model[k].shape != state_dict[k].shape:
+            print(f"Removing key {k} from pretrained checkpoint")
+            del checkpoint_model[k]
+    pe = checkpoint_model.get("pos_embed")
+    if pe is not None and "pos_embed" in state_dict and pe.shape != state_dict["pos_embed"].shape:
+        grid = model.patch_embed.grid_size
+        checkpoint_model["pos_embed"] = resample_abs_pos_embed(pe, (grid[0], grid[1]), num_prefix_tokens=model.num_prefix_tokens)
+    return load_state_dict(model, checkpoint_model, prefix=model_prefix)
