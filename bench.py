@@ -28,6 +28,7 @@ FLOP_PER_IMAGE = {"vit_base_patch16_224": 105.38e9}          # train = 6 x forwa
 GEMM_FLOP_PER_IMAGE = {"vit_base_patch16_224": 101.09e9}     # the linears/patch/head share (attention products: 4.29e9)
 NT_TRAFFIC_BYTES_PER_LAUNCH = 1.14e9     # 2 x 383.9e6 (FETCH_SIZE) + 372.2e6 (WRITE_SIZE), profiles/r1_pmc_hbm.md
 PEAK_BF16_TFLOPS = 2500.0                                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0                                        # HBM3E spec (6.3 TB/s measured achievable, same guide)
 
 
 def log(*a):
@@ -191,6 +192,18 @@ def main():
                          "launches": tn_n, "avg_launch_ms": round(tn_ms / max(tn_n, 1), 4)},
                 "gemm_share_of_step": round((nt_ms + tn_ms) / (elapsed * 1e3), 3),
             }
+            # the HBM-bound kernels of the step, same event brackets: algorithmic bytes / launch time against the 8 TB/s peak
+            hbm = []
+            for name, kind in (("ln_fwd_kernel (LayerNorm forward)", ops.PROF_LN_FWD), ("ln_bwd_kernel (LayerNorm backward + residual-gradient add + scaled copy)", ops.PROF_LN_BWD),
+                               ("attn_fwd_kernel (fused softmax attention forward)", ops.PROF_ATTN_FWD),
+                               ("attn_bwd_res_kernel (fused attention backward)", ops.PROF_ATTN_BWD), ("adamw_kernel (fused AdamW + bf16 copy-out)", ops.PROF_ADAMW)):
+                k_ms, k_bytes, k_n = ops.prof_read(kind)
+                if k_n:
+                    gbs = k_bytes / (k_ms * 1e-3) / 1e9
+                    hbm.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round(gbs / PEAK_HBM_GBS, 4), "launches": k_n, "avg_launch_us": round(k_ms / k_n * 1e3, 1),
+                                "bytes_per_launch_avg": round(k_bytes / k_n)})
+            result["hbm_rooflines"] = hbm
             ops.prof_reset()
     if world > 1:
         dist.barrier()

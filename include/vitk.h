@@ -44,13 +44,23 @@ enum {
 int vitk_version(void);
 const char* vitk_last_error(void);
 
-/* ---- profiling of the dominant kernel family (GEMM): per-launch hipEvent brackets on the launch stream.
- * No counterpart in the reference (it has no profiling hooks, engine.py:157-195 only keeps wall-clock deltas). */
+/* ---- profiling: per-launch hipEvent brackets on the launch stream around the main kernel of each family.
+ * No counterpart in the reference (it has no profiling hooks, engine.py:157-195 only keeps wall-clock deltas).
+ * Work recorded per launch: floating-point operations 2*M*N*K for the GEMM kinds (MFMA-bound), algorithmic bytes for the
+ * others (HBM-bound): LayerNorm forward 4 B/element, backward 6 B/element + 2 per fused residual-gradient read and per
+ * scaled copy; attention forward reads qkv and writes out, backward reads qkv, out, dout and writes dqkv; AdamW 30 B per
+ * parameter with the bf16 copy-out (28 without), + 8 with EMA. */
 #define VITK_PROF_ALL (-1)
 #define VITK_PROF_GEMM_NT 0
 #define VITK_PROF_GEMM_TN 1
-int vitk_prof_enable(int on);                                  /* 1: bracket every GEMM launch with events */
-/* sums over the recorded launches of one kind (or all): waits for their events; records stay until vitk_prof_reset() */
+#define VITK_PROF_LN_FWD 2
+#define VITK_PROF_LN_BWD 3
+#define VITK_PROF_ATTN_FWD 4
+#define VITK_PROF_ATTN_BWD 5
+#define VITK_PROF_ADAMW 6
+int vitk_prof_enable(int on);                                  /* 1: bracket the launches listed above with events */
+/* sums over the recorded launches of one kind (or all): waits for their events; records stay until vitk_prof_reset().
+ * total_flop carries the work unit of the kind (operations or bytes). */
 int vitk_prof_read(int kind, double* total_ms, double* total_flop, int64_t* launches);
 int vitk_prof_reset(void);
 

@@ -12,7 +12,10 @@ from pathlib import Path
 # runtime (the one torch ships and initialises); loading ours first pulls in /opt/rocm's copy and the device is not found.
 import torch  # noqa: F401
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libvitk.so"
+import os
+
+# VITK_LIB_PATH points at another build of the same library (A/B timing of a kernel change); default: the in-tree build
+LIB_PATH = Path(os.environ.get("VITK_LIB_PATH") or (Path(__file__).resolve().parent / "csrc" / "libvitk.so"))
 
 _p = C.c_void_p
 _i = C.c_int

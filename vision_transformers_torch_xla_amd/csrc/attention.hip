@@ -11,6 +11,9 @@
 // qkv is nn.Linear(D,3D)'s output [B*N, 3*H*64]; column = which*H*64 + head*64 + d.
 #include "common.h"
 
+bool vitk_prof_begin(void* stream, double flop, int kind);
+void vitk_prof_end(void* stream);
+
 #define HD 64   // head dim
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -29,6 +32,18 @@ static __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 static __device__ __forceinline__ int swz(int row, int col) {
     return row * HD + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7));
 }
+
+// Output rows.  After the transposed products a lane holds, for row lr of a 16-row tile, four 8-byte pieces: 4 consecutive bf16
+// at column 16*dt + 4*lg.  Stores cost per instruction, not per byte, so pieces are paired first: two exchanges between
+// neighbouring 16-lane rows (v_permlane16_swap: rows 1 and 3 of the first operand <-> rows 0 and 2 of the second) turn the pieces
+// of column tiles dtA and dtB into ONE 16-byte piece per lane - lanes with even lg get columns 16*dtA + 8*(lg/2) .. +7, lanes with
+// odd lg columns 16*dtB + 8*(lg/2) .. +7.  Every lane of the wave must take part in the exchange (call it outside row guards).
+static __device__ __forceinline__ u32x4_t pair_pieces(uint2 pA, uint2 pB) {
+    const auto rx = __builtin_amdgcn_permlane16_swap(pA.x, pB.x, false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(pA.y, pB.y, false, false);
+    return (u32x4_t){rx[0], ry[0], rx[1], ry[1]};
+}
+static __device__ __forceinline__ int pair_col(int dtA, int dtB, int lg) { return 16 * ((lg & 1) ? dtB : dtA) + 8 * (lg >> 1); }
 
 // ------------------------------------------------------------------------------------------------ forward
 // One workgroup per (batch, head).  K and V go global -> LDS by DMA (no staging registers), both as [key][64] with the
@@ -145,15 +160,17 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
         }
         // o[dt][r] = O^T[d = 16dt + 4lg + r][q = lr]
         const int q = qt * 16 + lr;
-        if (q < N) {
-            bf16_t* op = out + ((size_t)b * N + q) * D + h * HD + 4 * lg;
+        uint2 pc[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 w;
-                w.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
-                w.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-                *reinterpret_cast<uint2*>(op + dt * 16) = w;
-            }
+        for (int dt = 0; dt < 4; ++dt) {
+            pc[dt].x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
+            pc[dt].y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+        }
+        const u32x4_t w01 = pair_pieces(pc[0], pc[1]), w23 = pair_pieces(pc[2], pc[3]);
+        if (q < N) {
+            bf16_t* op = out + ((size_t)b * N + q) * D + h * HD;
+            *reinterpret_cast<u32x4_t*>(op + pair_col(0, 1, lg)) = w01;
+            *reinterpret_cast<u32x4_t*>(op + pair_col(2, 3, lg)) = w23;
             if (lg == 0) lse[((size_t)b * H + h) * N + q] = (mx * c2 + __builtin_amdgcn_logf(sum)) * 0.69314718055994530942f;
         }
         qf[0] = qn[0];
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
     bf16_t* R0 = reinterpret_cast<bf16_t*>(attn_smem);     // Q, then K
     bf16_t* R1 = R0 + NPAD * HD;                            // dO, then V
     float* lse_s = reinterpret_cast<float*>(R1 + NPAD * HD);   // [NPAD] lse * log2(e), +inf past N
-    float* dl_s = lse_s + NPAD;                                // [NPAD] delta
+    float* dl_s = lse_s + NPAD;                                // [NPAD] delta * scale
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,7 +261,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             part += __shfl_xor(part, 2, 64);
             part += __shfl_xor(part, 4, 64);
             if ((it & 7) == 0) {
-                dl_s[q] = part;
+                dl_s[q] = part * scale;
                 lse_s[q] = q < N ? lv[i] * 1.44269504088896340736f : INFINITY;
             }
         }
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             part += __shfl_xor(part, 2, 64);
             part += __shfl_xor(part, 4, 64);
             if ((it & 7) == 0) {
-                dl_s[q] = part;
+                dl_s[q] = part * scale;
                 lse_s[q] = q < N ? lv * 1.44269504088896340736f : INFINITY;
             }
         }
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
                     for (int r = 0; r < 4; ++r) {
                         const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, -lq4[r]));
                         pt[qi][r] = pp;
-                        ds[qi][r] = pp * (dpacc[r] - dq4[r]) * scale;
+                        ds[qi][r] = pp * __builtin_fmaf(dpacc[r], scale, -dq4[r]);
                     }
                 }
                 pa = pack8(pt[0], pt[1]);     // contraction slot (lg, j): q = 4lg + j | 16 + 4lg + j - 4
@@ -343,16 +360,20 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         }
         // lane holds dK^T / dV^T [d = 16dt + 4lg + r][key = lr]
         const int key = kt * 16 + lr;
-        if (key < N) {
-            bf16_t* rowp = dqkv + ((size_t)b * N + key) * ld + h * HD + 4 * lg;
+        uint2 pk[4], pv[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 wk, wv;
-                wk.x = pack2bf(dk[dt][0], dk[dt][1]); wk.y = pack2bf(dk[dt][2], dk[dt][3]);
-                wv.x = pack2bf(dv[dt][0], dv[dt][1]); wv.y = pack2bf(dv[dt][2], dv[dt][3]);
-                *reinterpret_cast<uint2*>(rowp + D + dt * 16) = wk;
-                *reinterpret_cast<uint2*>(rowp + 2 * D + dt * 16) = wv;
-            }
+        for (int dt = 0; dt < 4; ++dt) {
+            pk[dt].x = pack2bf(dk[dt][0], dk[dt][1]); pk[dt].y = pack2bf(dk[dt][2], dk[dt][3]);
+            pv[dt].x = pack2bf(dv[dt][0], dv[dt][1]); pv[dt].y = pack2bf(dv[dt][2], dv[dt][3]);
+        }
+        const u32x4_t k01 = pair_pieces(pk[0], pk[1]), k23 = pair_pieces(pk[2], pk[3]);
+        const u32x4_t v01 = pair_pieces(pv[0], pv[1]), v23 = pair_pieces(pv[2], pv[3]);
+        if (key < N) {
+            bf16_t* rowp = dqkv + ((size_t)b * N + key) * ld + h * HD;
+            *reinterpret_cast<u32x4_t*>(rowp + D + pair_col(0, 1, lg)) = k01;
+            *reinterpret_cast<u32x4_t*>(rowp + D + pair_col(2, 3, lg)) = k23;
+            *reinterpret_cast<u32x4_t*>(rowp + 2 * D + pair_col(0, 1, lg)) = v01;
+            *reinterpret_cast<u32x4_t*>(rowp + 2 * D + pair_col(2, 3, lg)) = v23;
         }
     }
     (void)TPW;
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, nl));
-                    ds[e][r] = pp * (dpacc[r] - dl) * scale;
+                    ds[e][r] = pp * __builtin_fmaf(dpacc[r], scale, -dl);
                 }
             }
             const bf16x8 dsb = pack8(ds[0], ds[1]);
@@ -428,15 +449,17 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         }
         if ((qt + WAVES) * 16 < N) load_q(qt + WAVES, qf, dof);
         // dq[dt][r] = dQ^T[d = 16dt + 4lg + r][q = lr]
-        if (q < N) {
-            bf16_t* rowp = dqkv + ((size_t)b * N + q) * ld + h * HD + 4 * lg;
+        uint2 pq[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 w;
-                w.x = pack2bf(dq[dt][0], dq[dt][1]);
-                w.y = pack2bf(dq[dt][2], dq[dt][3]);
-                *reinterpret_cast<uint2*>(rowp + dt * 16) = w;
-            }
+        for (int dt = 0; dt < 4; ++dt) {
+            pq[dt].x = pack2bf(dq[dt][0], dq[dt][1]);
+            pq[dt].y = pack2bf(dq[dt][2], dq[dt][3]);
+        }
+        const u32x4_t q01 = pair_pieces(pq[0], pq[1]), q23 = pair_pieces(pq[2], pq[3]);
+        if (q < N) {
+            bf16_t* rowp = dqkv + ((size_t)b * N + q) * ld + h * HD;
+            *reinterpret_cast<u32x4_t*>(rowp + pair_col(0, 1, lg)) = q01;
+            *reinterpret_cast<u32x4_t*>(rowp + pair_col(2, 3, lg)) = q23;
         }
     }
 }
@@ -451,6 +474,7 @@ int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int
     const size_t smem = (size_t)2 * maxt * 16 * HD * sizeof(bf16_t);
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done[40] = {false};
+    const bool pr = vitk_prof_begin(stream, 8.0 * (double)B * (double)N * (double)H * HD, VITK_PROF_ATTN_FWD);
 #define VITK_FWD_CASE(T, W, E)                                                                                              \
     case T: {                                                                                                               \
         if (!attr_done[T]) {                                                                                                \
@@ -468,6 +492,7 @@ int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int
         default: vitk_set_error("attention_fwd: unsupported token count %d", N); return VITK_EINVAL;
     }
 #undef VITK_FWD_CASE
+    if (pr) vitk_prof_end(stream);
     return vitk_check_launch("attention_fwd");
 }
 
@@ -487,6 +512,7 @@ int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const
     const size_t smem = (size_t)2 * maxt * 16 * HD * sizeof(bf16_t) + (size_t)2 * maxt * 16 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done[40] = {false};
+    const bool pr = vitk_prof_begin(stream, 16.0 * (double)B * (double)N * (double)H * HD, VITK_PROF_ATTN_BWD);
 #define VITK_BWD_CASE(T, W, E)                                                                                                 \
     case T: {                                                                                                               \
         if (!attr_done[T]) {                                                                                                \
@@ -506,6 +532,7 @@ int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const
         default: vitk_set_error("attention_bwd: unsupported token count %d", N); return VITK_EINVAL;
     }
 #undef VITK_BWD_CASE
+    if (pr) vitk_prof_end(stream);
     return vitk_check_launch("attention_bwd");
 }
 

@@ -3,9 +3,22 @@
 // plus 2 B/element when the residual gradient is fused in.
 #include "common.h"
 
+bool vitk_prof_begin(void* stream, double flop, int kind);
+void vitk_prof_end(void* stream);
+
 #define LN_ROWS_PER_BLOCK 4   // 4 waves of 64 lanes
 #define LN_MAX_BLOCKS 2048
 
+typedef __attribute__((ext_vector_type(4))) unsigned ln_u4;
+static __device__ __forceinline__ void ln_unpack(const ln_u4 r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+// The row loop is software-pipelined: the loads of the wave's next row are issued before the current row is reduced, so a
+// wave always has a row in flight (one row per wave at a time leaves too few bytes in flight to cover the HBM latency).
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ y,
@@ -14,28 +27,48 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D >> 3;
     const float invD = 1.0f / (float)D;
-    for (int row = blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * LN_ROWS_PER_BLOCK) {
-        const bf16_t* xr = x + (size_t)row * D;
+    const int stride = gridDim.x * LN_ROWS_PER_BLOCK;
+    int row = blockIdx.x * LN_ROWS_PER_BLOCK + wave;
+    if (row >= M) return;
+    int cc[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        ok[i] = c < nvec;
+        cc[i] = ok[i] ? c : 0;            // lanes past the row re-read chunk 0 and ignore it
+    }
+    // gamma and beta of the lane's columns stay in registers for all rows of the wave
+    float g[NV][8], bt[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + 8 * cc[i]);
+        const float4 g1 = *reinterpret_cast<const float4*>(gamma + 8 * cc[i] + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + 8 * cc[i]);
+        const float4 b1 = *reinterpret_cast<const float4*>(beta + 8 * cc[i] + 4);
+        g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w; g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
+        bt[i][0] = b0.x; bt[i][1] = b0.y; bt[i][2] = b0.z; bt[i][3] = b0.w; bt[i][4] = b1.x; bt[i][5] = b1.y; bt[i][6] = b1.z; bt[i][7] = b1.w;
+    }
+    ln_u4 cur[NV], nxt[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) cur[i] = *reinterpret_cast<const ln_u4*>(x + (size_t)row * D + 8 * cc[i]);
+    for (; row < M; row += stride) {
+        const int nrow = row + stride < M ? row + stride : row;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) nxt[i] = *reinterpret_cast<const ln_u4*>(x + (size_t)nrow * D + 8 * cc[i]);
         float v[NV][8];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nvec) {
-                load8(xr + 8 * c, v[i]);
+            ln_unpack(cur[i], v[i]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += v[i][j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-            }
+            for (int j = 0; j < 8; ++j) { v[i][j] = ok[i] ? v[i][j] : 0.f; s += v[i][j]; }
         }
         const float mu = wave_sum(s) * invD;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int c = lane + 64 * i;
-            if (c < nvec) {
+            if (ok[i]) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
             }
@@ -46,20 +79,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + 64 * i;
-            if (c < nvec) {
-                const float4 g0 = *reinterpret_cast<const float4*>(gamma + 8 * c);
-                const float4 g1 = *reinterpret_cast<const float4*>(gamma + 8 * c + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(beta + 8 * c);
-                const float4 b1 = *reinterpret_cast<const float4*>(beta + 8 * c + 4);
-                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            if (ok[i]) {
                 float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+                for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g[i][j] + bt[i][j];
                 store8(yr + 8 * c, o);
             }
         }
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) cur[i] = nxt[i];
     }
 }
 
@@ -68,13 +97,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 // fixed order (deterministic).  Every global load of a row (x, dy, the residual gradient) is issued before the
 // first is used.  With rowscale the kernel also writes dxs = rowscale[row / rows_per_group] * dx, the gradient
 // that enters the next residual branch under stochastic depth (one extra store instead of a separate pass).
-typedef __attribute__((ext_vector_type(4))) unsigned ln_u4;
-static __device__ __forceinline__ void ln_unpack(const ln_u4 r, float (&v)[8]) {
-    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
-    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
-    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
-}
 
 template <int NV, bool RES, bool SCALED>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
@@ -94,16 +116,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; g[i][j] = (c < nvec) ? gamma[8 * c + j] : 0.f; }
     }
-    for (int row = blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * LN_ROWS_PER_BLOCK) {
-        const size_t off = (size_t)row * D;
-        ln_u4 rx[NV], rd[NV], rr[NV];
+    const int stride = gridDim.x * LN_ROWS_PER_BLOCK;
+    int row = blockIdx.x * LN_ROWS_PER_BLOCK + wave;
+    int cc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        cc[i] = c < nvec ? c : 0;        // lanes past the row re-read chunk 0 and ignore it
+    }
+    ln_u4 rx[NV], rd[NV], rr[NV], nx[NV], nd[NV], nr[NV];
+    if (row < M) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int c = lane + 64 * i;
-            const int cc = c < nvec ? c : 0;        // lanes past the row re-read chunk 0 and ignore it
-            rx[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(x + off + 8 * cc));
-            rd[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dy + off + 8 * cc));
-            if (RES) rr[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dres + off + 8 * cc));
+            const size_t o = (size_t)row * D + 8 * cc[i];
+            rx[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(x + o));
+            rd[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dy + o));
+            if (RES) rr[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dres + o));
+        }
+    }
+    for (; row < M; row += stride) {
+        const size_t off = (size_t)row * D;
+        {   // the next row's loads travel under this row's arithmetic (the last trip re-reads its own row)
+            const int nrow = row + stride < M ? row + stride : row;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const size_t o = (size_t)nrow * D + 8 * cc[i];
+                nx[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(x + o));
+                nd[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dy + o));
+                if (RES) nr[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dres + o));
+            }
         }
         const float mu = mean[row], rs = rstd[row];
         float sc = 1.0f;
@@ -157,6 +198,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { rx[i] = nx[i]; rd[i] = nd[i]; if (RES) rr[i] = nr[i]; }
     }
     // fold the 4 waves
     float* sg = ln_smem + (size_t)wave * 2 * D;
@@ -214,10 +257,12 @@ int vitk_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
                  "layernorm_fwd: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int grid = ln_grid(M);
+    const bool pr = vitk_prof_begin(stream, 4.0 * (double)M * (double)D, VITK_PROF_LN_FWD);
     if (D <= 512)
         ln_fwd_kernel<1><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
     else
         ln_fwd_kernel<2><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+    if (pr) vitk_prof_end(stream);
     return vitk_check_launch("layernorm_fwd");
 }
 
@@ -247,6 +292,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* mean, const f
     ln_bwd_kernel<NV, R, S><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, \
                                                     (bf16_t*)dx, rowscale, rows_per_group, (bf16_t*)dxs, partial, M, D)
     const int sel = (D <= 512 ? 0 : 4) + (dres ? 2 : 0) + (rowscale ? 1 : 0);
+    const bool pr = vitk_prof_begin(stream, (6.0 + (dres ? 2.0 : 0.0) + (rowscale ? 2.0 : 0.0)) * (double)M * (double)D, VITK_PROF_LN_BWD);
     switch (sel) {
         case 0: VITK_LN_BWD(1, false, false); break;
         case 1: VITK_LN_BWD(1, false, true); break;
@@ -258,6 +304,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* mean, const f
         default: VITK_LN_BWD(2, true, true); break;
     }
 #undef VITK_LN_BWD
+    if (pr) vitk_prof_end(stream);
     int rc = vitk_check_launch("layernorm_bwd");
     if (rc) return rc;
     ln_bwd_reduce_kernel<<<(2 * D + 15) / 16, 1024, 0, s>>>(partial, grid, D, dgamma, dbeta, accumulate);

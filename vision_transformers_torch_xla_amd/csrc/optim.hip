@@ -2,6 +2,9 @@
 // [+ EMA read/write 8 B].  HBM-bound.  Arithmetic follows torch.optim.AdamW (decoupled decay, bias-corrected).
 #include "common.h"
 
+bool vitk_prof_begin(void* stream, double flop, int kind);
+void vitk_prof_end(void* stream);
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb, float* __restrict__ ema,
                                                     float ema_decay, float omd, int64_t n, float beta2, float omb1, float omb2, float eps,
@@ -144,8 +147,10 @@ int vitk_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, 
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
+    const bool pr = vitk_prof_begin(stream, (28.0 + (p_bf16 ? 2.0 : 0.0) + (ema ? 8.0 : 0.0)) * (double)n, VITK_PROF_ADAMW);
     adamw_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, ema, (float)ema_decay, omd, n, (float)beta2, omb1, omb2,
                                                               (float)eps, decay_mul, step_size, inv_bc2_sqrt, grad_scale);
+    if (pr) vitk_prof_end(stream);
     return vitk_check_launch("adamw_step");
 }
 

@@ -349,11 +349,11 @@ def prof_enable(on: bool):
     check(_lib.load().vitk_prof_enable(int(on)), "prof_enable")
 
 
-PROF_ALL, PROF_GEMM_NT, PROF_GEMM_TN = -1, 0, 1
+PROF_ALL, PROF_GEMM_NT, PROF_GEMM_TN, PROF_LN_FWD, PROF_LN_BWD, PROF_ATTN_FWD, PROF_ATTN_BWD, PROF_ADAMW = -1, 0, 1, 2, 3, 4, 5, 6
 
 
 def prof_read(kind=PROF_ALL):
-    """(total ms, total flop, launches) of the event-bracketed GEMM launches of one kind"""
+    """(total ms, total work, launches) of the event-bracketed launches of one kind; work = flop for the GEMM kinds, bytes else"""
     import ctypes as C
     ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
     check(_lib.load().vitk_prof_read(kind, C.byref(ms), C.byref(fl), C.byref(n)), "prof_read")
