@@ -313,7 +313,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         f32x4 dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 1
+        // up to 224 tokens the 32-query steps are unrolled: every LDS address becomes base + immediate (the rolled loop spends
+        // a third of its vector instructions on address arithmetic)
+#pragma unroll(MAXT <= 14 ? MAXT / 2 : 1)
         for (int st = 0; st < MAXT / 2; ++st) {
             const bf16_t* Qp = R0 + st * 32 * HD;
             const bf16_t* dOp = R1 + st * 32 * HD;
@@ -347,7 +349,6 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
                 pa = pack8(pt[0], pt[1]);     // contraction slot (lg, j): q = 4lg + j | 16 + 4lg + j - 4
                 dsa = pack8(ds[0], ds[1]);
             }
-            __builtin_amdgcn_sched_barrier(0);
             // stage 2: dV^T += dO^T P, dK^T += Q^T dS
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
                 dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr, pa, dv[dt], 0, 0, 0);
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsa, dk[dt], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);      // keeps the unrolled steps from being hoisted into each other (spills)
         }
         // lane holds dK^T / dV^T [d = 16dt + 4lg + r][key = lr]
         const int key = kt * 16 + lr;
