@@ -36,17 +36,26 @@ def log(*a):
 
 
 class SyntheticLoader:
-    """K identical-shape batches that already live in HBM (generated once per rank with seed + rank)."""
+    """K identical-shape batches that already live in HBM (generated once per rank with seed + rank).
 
-    def __init__(self, samples, targets, n):
+    prof_every > 0: the launches of every prof_every-th step are bracketed with HIP events (the per-kernel roofline figures
+    are averages over those steps of the timed region); bracketing every launch of every step costs 2-3 % of the step
+    time, because an event between two kernels keeps the second from starting under the first one's tail."""
+
+    def __init__(self, samples, targets, n, prof_every=0, prof_switch=None):
         self.samples, self.targets, self.n = samples, targets, n
+        self.prof_every, self.prof_switch = prof_every, prof_switch
 
     def __len__(self):
         return self.n
 
     def __iter__(self):
-        for _ in range(self.n):
+        for i in range(self.n):
+            if self.prof_every:
+                self.prof_switch(i % self.prof_every == 0)
             yield self.samples, self.targets
+        if self.prof_every:
+            self.prof_switch(False)
 
 
 def cpu_baseline(batch=16, steps=2, threads=None):
@@ -79,6 +88,7 @@ def main():
     ap.add_argument("--model", default="vit_base_patch16_224")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prof-every", type=int, default=5, help="bracket the kernel launches of every n-th timed step with HIP events")
     args = ap.parse_args()
 
     if os.environ.get("VITK_BENCH_WATCHDOG"):        # debugging aid: dump every thread's stack and exit if the run stalls
@@ -131,9 +141,9 @@ def main():
     samples = torch.randn(args.batch, 3, 224, 224, generator=g, device=device)
     targets = torch.randint(0, 1000, (args.batch,), generator=g, device=device)
 
-    def run(nsteps, start):
+    def run(nsteps, start, prof_every=0):
         with contextlib.redirect_stdout(sys.stderr):
-            return engine.train_one_epoch(model, criterion, SyntheticLoader(samples, targets, nsteps), optimizer, device, 0, None, 0,
+            return engine.train_one_epoch(model, criterion, SyntheticLoader(samples, targets, nsteps, prof_every, ops.prof_enable), optimizer, device, 0, None, 0,
                                           None, None, start_steps=start, lr_schedule_values=lr_sched, wd_schedule_values=wd_sched,
                                           num_training_steps_per_epoch=nsteps, update_freq=1, log_freq=10)
 
@@ -141,12 +151,11 @@ def main():
     want_roof = not args.no_roofline
     if want_roof:
         ops.prof_reset()
-        ops.prof_enable(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    stats = run(args.steps, args.warmup)
+    stats = run(args.steps, args.warmup, args.prof_every if want_roof else 0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -190,7 +199,8 @@ def main():
                 "flop_per_launch_avg": round(nt_fl / max(nt_n, 1) / 1e9, 2),
                 "also": {"kernel": "gemm_tnb_kernel / gemm_tn_kernel (weight gradients)", "achieved": round(tn_fl / (tn_ms * 1e-3) / 1e12, 1) if tn_ms > 0 else 0.0,
                          "launches": tn_n, "avg_launch_ms": round(tn_ms / max(tn_n, 1), 4)},
-                "gemm_share_of_step": round((nt_ms + tn_ms) / (elapsed * 1e3), 3),
+                "sampled_steps": len(range(0, args.steps, args.prof_every)),
+                "gemm_share_of_step": round((nt_ms + tn_ms) / (elapsed * 1e3 * len(range(0, args.steps, args.prof_every)) / args.steps), 3),
             }
             # the HBM-bound kernels of the step, same event brackets: algorithmic bytes / launch time against the 8 TB/s peak
             hbm = []
