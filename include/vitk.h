@@ -68,6 +68,10 @@ int vitk_prof_reset(void);
  * models/vision_transformer.py:148,163,530,616.  x,y bf16 [M,D]; gamma,beta fp32 [D]; mean,rstd fp32 [M]. D%8==0, D<=1024 */
 int vitk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        int M, int D, float eps, void* stream);
+/* The same over a compact set of samples: output row r (r < M, M = kept samples * rows_per_sample) normalises input row
+ * sample_map[r / rows_per_sample] * rows_per_sample + r % rows_per_sample; y, mean and rstd are compact. */
+int vitk_layernorm_fwd_gather(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                              int M, int D, float eps, const int* sample_map, int rows_per_sample, void* stream);
 /* dx_bf16 = LN'(dy) (+ dres_bf16 if non-null).  dgamma/dbeta fp32 [D]: overwritten (accumulate=0) or added to.
  * workspace: vitk_layernorm_bwd_workspace(M,D) bytes. */
 size_t vitk_layernorm_bwd_workspace(int M, int D);
@@ -82,6 +86,15 @@ int vitk_layernorm_bwd_scaled(const void* dy, const void* x, const float* mean, 
                               float* dgamma, float* dbeta, int accumulate, int M, int D, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* Backward over M FULL rows where dy, mean and rstd are compact over the samples that took the branch: in_inv[sample] is
+ * the sample's compact index or -1 (then dx = dres for its rows, and it adds nothing to dgamma / dbeta); with rowscale
+ * (indexed by full sample) dx_scaled receives rowscale[sample] * dx compactly for the samples with out_inv[sample] >= 0
+ * (out_inv null: all samples, full rows).  in_inv null: dy is full. */
+int vitk_layernorm_bwd_gather(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                              const void* dres, void* dx, const float* rowscale, int rows_per_sample, void* dx_scaled,
+                              const int* in_inv, const int* out_inv, float* dgamma, float* dbeta, int accumulate, int M,
+                              int D, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- GEMM, bf16 MFMA, fp32 accumulate.
  * vitk_gemm_nt: C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue.  Replaces nn.Linear forward/dgrad inside timm
  * Attention.qkv/.proj and Mlp.fc1/.fc2 (models/vision_transformer.py:149-159,164-171), the head (:618,990) and the
@@ -93,6 +106,14 @@ int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ld
 /* vitk_gemm_tn: C[N,K] (fp32) = A[M,N]^T * B[M,K] (weight gradient, contraction over the M rows), split over M into
  * slabs that a deterministic second kernel reduces; optionally also colsum(A) -> dbias[N].  accumulate: C += .
  * N%8==0, K%8==0, lda/ldb%8==0, ldc%4==0.  workspace: vitk_gemm_tn_workspace(M,N,K). */
+/* bias + residual epilogue with the output (and residual) rows scattered by sample: GEMM row m, which belongs to compact
+ * sample m / rows_per_sample, goes to row sample_map[m / rows_per_sample] * rows_per_sample + m % rows_per_sample of C and res.
+ * Stochastic depth (timm DropPath, models/vision_transformer.py:161,173,176-177) multiplies the branch of a dropped sample by 0:
+ * with this entry point the branch is computed for the kept samples only (A is compact) and lands in their rows; the rows of
+ * the dropped samples are carried over by vitk_copy_samples.  Same results, less work. */
+int vitk_gemm_nt_res_scatter(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                             const float* bias, const void* res, int ldres, const float* rowscale, int rows_per_group,
+                             const int* sample_map, int rows_per_sample, void* stream);
 size_t vitk_gemm_tn_workspace(int M, int N, int K);
 int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                  float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
@@ -129,8 +150,14 @@ int vitk_scatter_rows(const void* dy, void* dx, int B, int N, int D, int token, 
  * patch-embedding weight gradient; inverse of the torch.cat at models/vision_transformer.py:770-778) */
 int vitk_slice_tokens(const void* x, void* y, int B, int N, int D, int first, void* stream);
 
+/* dst[s] = src[s] for the whole samples s in sample_list (device array of `count` ints), bf16 [samples, elems_per_sample] */
+int vitk_copy_samples(const void* src, void* dst, const int* sample_list, int count, int64_t elems_per_sample, void* stream);
+
 /* ---- elementwise helpers */
 int vitk_rowscale(const void* x, const float* rowscale, int rows_per_group, void* y, int M, int D, void* stream);
+/* the same, compact over nk samples: y[c*rpg + t] = rowscale[sample_map[c]] * x[sample_map[c]*rpg + t] */
+int vitk_rowscale_gather(const void* x, const float* rowscale, int rows_per_group, const int* sample_map, int nk, void* y,
+                         int D, void* stream);
 int vitk_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int vitk_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 int vitk_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);

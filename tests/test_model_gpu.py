@@ -64,13 +64,20 @@ def _gradvec(m, ref):
 
 
 # --------------------------------------------------------------------------------------- (1) stage-wise, 1e-3
-def test_forward_stagewise_identical_inputs(device):
+@pytest.mark.parametrize("compact", [True, False])
+def test_forward_stagewise_identical_inputs(device, compact):
+    """compact: a residual branch is computed for the samples that keep it only (its intermediates are compact batches);
+    otherwise for every sample and multiplied by the per-sample factor, as timm's DropPath does"""
     from oracle import ref_ops as R
     ref, m = _pair("vit_tiny_patch16_224", device, depth=2, dpr=0.2)
+    m._compact_droppath = compact
     B = 3
     x, _ = _batch(B, 224, 40, 5)
     ref.train(); m.train()
     scales = ref.make_drop_scales(B, generator=torch.Generator().manual_seed(1))
+    scales[1][0][0] = 0.0           # make sure both branches of block 1 drop a sample (different ones)
+    scales[1][1][2] = 0.0
+    scales[1][1][0] = 1.25
     m._forced_drop_scales = scales
     with torch.no_grad():
         m._sync_weights()
@@ -90,17 +97,30 @@ def test_forward_stagewise_identical_inputs(device):
             blk = ref.blocks[li]
             sc1 = scales[li][0].reshape(B, 1, 1) if scales[li][0] is not None else 1.0
             sc2 = scales[li][1].reshape(B, 1, 1) if scales[li][1] is not None else 1.0
-            X, Y1, QKV, O, X2, Y2, Hh, A = [cpu(t).reshape(B, N, -1) for t in (xi, y1, qkv, o, x2, y2, h, a)]
+            X, X2 = cpu(xi).reshape(B, N, D), cpu(x2).reshape(B, N, D)
             X3 = cpu(saved["layers"][li + 1][0]).reshape(B, N, D) if li + 1 < len(saved["layers"]) else None
-            errs[f"{li}.ln1"] = rel_l2(Y1, rb(R.layernorm(X, blk.norm1.weight, blk.norm1.bias)))
+            # the samples a branch was computed for: all of them, or the kept ones (compact intermediates)
+            k1 = s1.kept.cpu().long() if (s1 is not None and s1.compact) else torch.arange(B)
+            k2 = s2.kept.cpu().long() if (s2 is not None and s2.compact) else torch.arange(B)
+            assert (s1 is not None and s1.compact) == (compact and li == 1) and len(k1) == (2 if compact and li == 1 else B)
+            Y1, QKV, O = [cpu(t).reshape(len(k1), N, -1) for t in (y1, qkv, o)]
+            Y2, Hh, A = [cpu(t).reshape(len(k2), N, -1) for t in (y2, h, a)]
+            errs[f"{li}.ln1"] = rel_l2(Y1, rb(R.layernorm(X[k1], blk.norm1.weight, blk.norm1.bias)))
             errs[f"{li}.qkv"] = rel_l2(QKV, rb(Y1 @ wq(blk.attn.qkv.weight).t() + blk.attn.qkv.bias))
             errs[f"{li}.attn"] = rel_l2(O, R.attention(QKV, H, emulate=True))
-            errs[f"{li}.proj+res"] = rel_l2(X2, rb(X + sc1 * (O @ wq(blk.attn.proj.weight).t() + blk.attn.proj.bias)))
-            errs[f"{li}.ln2"] = rel_l2(Y2, rb(R.layernorm(X2, blk.norm2.weight, blk.norm2.bias)))
+            branch = torch.zeros(B, N, D)
+            branch[k1] = O @ wq(blk.attn.proj.weight).t() + blk.attn.proj.bias
+            errs[f"{li}.proj+res"] = rel_l2(X2, rb(X + sc1 * branch))
+            if isinstance(sc1, torch.Tensor):
+                dropped = (sc1.reshape(B) == 0).nonzero().flatten()
+                assert torch.equal(X2[dropped], X[dropped])             # a dropped sample passes through bit for bit
+            errs[f"{li}.ln2"] = rel_l2(Y2, rb(R.layernorm(X2[k2], blk.norm2.weight, blk.norm2.bias)))
             errs[f"{li}.fc1"] = rel_l2(Hh, rb(Y2 @ wq(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias))
             errs[f"{li}.gelu"] = rel_l2(A, rb(R.gelu(Hh)))
             if X3 is not None:
-                errs[f"{li}.fc2+res"] = rel_l2(X3, rb(X2 + sc2 * (A @ wq(blk.mlp.fc2.weight).t() + blk.mlp.fc2.bias)))
+                branch = torch.zeros(B, N, D)
+                branch[k2] = A @ wq(blk.mlp.fc2.weight).t() + blk.mlp.fc2.bias
+                errs[f"{li}.fc2+res"] = rel_l2(X3, rb(X2 + sc2 * branch))
         t = saved["tail"]
         pooled, f = cpu(t["pooled"]), cpu(t["f"])
         errs["fc_norm"] = rel_l2(f, rb(R.layernorm(pooled, ref.fc_norm.weight, ref.fc_norm.bias)))
@@ -110,15 +130,19 @@ def test_forward_stagewise_identical_inputs(device):
     assert not bad, bad
 
 
-def test_backward_stagewise_identical_inputs(device):
+@pytest.mark.parametrize("compact", [True, False])
+def test_backward_stagewise_identical_inputs(device, compact):
     """each half-block of the HIP backward vs autograd through the oracle's half-block, fed the HIP half-block's own
-    input activation and incoming gradient"""
+    input activation and incoming gradient; with and without computing a branch for its kept samples only"""
     ref, m = _pair("vit_tiny_patch16_224", device, depth=2, dpr=0.2)
+    m._compact_droppath = compact
     from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
     B = 4
     x, y = _batch(B, 224, 40, 9)
     ref.train(); m.train()
     scales = ref.make_drop_scales(B, generator=torch.Generator().manual_seed(2))
+    scales[1][0][:] = torch.tensor([1.25, 0.0, 1.25, 1.25])      # both branches of block 1 drop samples (different ones)
+    scales[1][1][:] = torch.tensor([0.0, 1.25, 1.25, 0.0])
     m._forced_drop_scales = scales
     m._bwd_taps = {}
     m.zero_grad()
@@ -334,3 +358,60 @@ def test_evaluate(device):
     assert set(got) == {"loss", "acc1", "acc5"}
     assert abs(got["loss"] - want["loss"]) <= E2E_TOL * abs(want["loss"])
     assert abs(got["acc1"] - want["acc1"]) <= 1e-6 and abs(got["acc5"] - want["acc5"]) <= 1e-6
+
+
+# ------------------------------------------------------------------------ (4) stochastic depth: compact == masked
+def test_droppath_compaction_equals_masked_compute(device):
+    """Computing a residual branch for its kept samples only gives what computing it for every sample and multiplying the
+    dropped ones by zero gives (timm DropPath): same logits, same gradients (weight gradients sum their rows in another
+    grouping, so they agree to fp32 summation order).  Includes a branch that every sample drops and one that none drops."""
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+    torch.manual_seed(3)
+    m = create_model("vit_small_patch16_224", num_classes=40, global_pool="avg", depth=3, drop_path_rate=0.3).to(device)
+    B = 6
+    x, y = _batch(B, 224, 40, 11)
+    k = 1.0 / 0.85
+    scales = [(None, None),
+              (torch.tensor([k, 0, k, k, 0, k]), torch.tensor([0.0] * 6)),                 # MLP branch of block 1: all dropped
+              (torch.tensor([k] * 6), torch.tensor([0, k, k, 0, 0, 0.0]))]                 # attention branch of block 2: none dropped
+    m.train()
+    res = {}
+    for compact in (False, True):
+        m._compact_droppath = compact
+        m._forced_drop_scales = scales
+        m.zero_grad()
+        out = m(x.to(device))
+        LabelSmoothingCrossEntropy(0.1)(out, y.to(device)).backward()
+        torch.cuda.synchronize()
+        res[compact] = (out.detach().clone(), m._flat["g"].clone())
+    assert rel_l2(res[True][0], res[False][0].cpu()) <= 1e-5
+    assert rel_l2(res[True][1], res[False][1].cpu()) <= 1e-4
+    # every parameter of the all-dropped branch has an exactly zero gradient in both modes
+    for n in ("mlp.fc1.weight", "mlp.fc2.bias", "norm2.weight"):
+        assert torch.count_nonzero(m._gview[f"blocks.1.{n}"]) == 0
+
+
+def test_random_droppath_plans(device):
+    """host-side draws: kept / dropped / inverse tables are consistent with the scale vector, for every branch of a step"""
+    from vision_transformers_torch_xla_amd.vit import create_model
+    torch.manual_seed(0)
+    m = create_model("vit_tiny_patch16_224", num_classes=40, global_pool="avg", depth=4, drop_path_rate=0.5).to(device)
+    m.train()
+    B = 32
+    plans = m._draw_drop_scales(B, device)
+    assert plans[0] == (None, None)                       # rate 0 in the first block
+    seen_drop = False
+    for pair in plans[1:]:
+        for br in pair:
+            sc = br.scale.cpu()
+            kept, dropped, inv = br.kept.cpu().long(), br.dropped.cpu().long(), br.inv.cpu().long()
+            assert br.nk == len(kept) and len(kept) + len(dropped) == B
+            assert torch.equal(torch.sort(torch.cat([kept, dropped]))[0], torch.arange(B))
+            assert (sc[kept] > 1.0).all() and (sc[dropped] == 0).all() and torch.equal(br.scale_c.cpu(), sc[kept])
+            assert torch.equal(inv[kept], torch.arange(len(kept))) and (inv[dropped] == -1).all()
+            assert torch.equal(kept, torch.sort(kept)[0])
+            seen_drop |= len(dropped) > 0
+    assert seen_drop
+    m.eval()
+    assert all(p == (None, None) for p in m._draw_drop_scales(B, device))

@@ -32,10 +32,13 @@ SIGNATURES = {
     "vitk_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "vitk_prof_reset": (_i, []),
     "vitk_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "vitk_layernorm_fwd_gather": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _i, _p]),
+    "vitk_layernorm_bwd_gather": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vitk_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "vitk_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vitk_layernorm_bwd_scaled": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vitk_gemm_nt": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p]),
+    "vitk_gemm_nt_res_scatter": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p]),
     "vitk_gemm_tn_workspace": (_sz, [_i, _i, _i]),
     "vitk_gemm_tn": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
     "vitk_attention_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
@@ -49,6 +52,8 @@ SIGNATURES = {
     "vitk_gather_rows": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vitk_scatter_rows": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vitk_slice_tokens": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vitk_copy_samples": (_i, [_p, _p, _p, _i, _i64, _p]),
+    "vitk_rowscale_gather": (_i, [_p, _p, _i, _p, _i, _p, _i, _p]),
     "vitk_rowscale": (_i, [_p, _p, _i, _p, _i, _i, _p]),
     "vitk_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
     "vitk_cast_bf16_to_f32": (_i, [_p, _p, _i64, _p]),

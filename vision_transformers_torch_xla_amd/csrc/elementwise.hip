@@ -308,6 +308,38 @@ __global__ void mixup_targets_kernel(const int64_t* __restrict__ target, float* 
     }
 }
 
+// dst[list[i]] = src[list[i]] for whole samples of `per8` 16-byte pieces each: the samples that skip a residual branch under
+// stochastic depth keep their activations (x + 0 * branch(x), timm DropPath as used at models/vision_transformer.py:176-177)
+__global__ void copy_samples_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int* __restrict__ list, int count,
+                                    size_t per8) {
+    const size_t total = (size_t)count * per8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = i / per8, e = i - k * per8;
+        const size_t o = (size_t)list[k] * per8 + e;
+        dst[o] = src[o];
+    }
+}
+
+// y[c * rpg + t][:] = rowscale[smap[c]] * x[smap[c] * rpg + t][:] for the nk samples of smap: the scaled gradient that enters a
+// residual branch, compact over the samples that took the branch
+__global__ void rowscale_gather_kernel(const bf16_t* __restrict__ x, const float* __restrict__ rowscale, int rows_per_group,
+                                       const int* __restrict__ smap, int nk, bf16_t* __restrict__ y, int D) {
+    const int nv = D / 8;
+    const size_t total = (size_t)nk * rows_per_group * nv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / nv;
+        const int c8 = (int)(i - row * nv) * 8;
+        const int c = (int)(row / rows_per_group), t = (int)(row - (size_t)c * rows_per_group);
+        const int smp = smap[c];
+        const float sc = rowscale[smp];
+        float v[8];
+        load8(x + ((size_t)smp * rows_per_group + t) * D + c8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= sc;
+        store8(y + row * D + c8, v);
+    }
+}
+
 extern "C" {
 
 int vitk_im2col_patches(const float* img, void* patches, int B, int C, int H, int W, int p, void* stream) {
@@ -450,6 +482,25 @@ int vitk_mixup_targets(const int64_t* target, float* out, int ldo, int B, int C,
     VITK_REQUIRE(target && out && B > 0 && C > 0 && ldo >= C, "mixup_targets: bad arguments");
     mixup_targets_kernel<<<B, 256, 0, (hipStream_t)stream>>>(target, out, ldo, B, C, lam, one_minus_lam, on_value, off_value);
     return vitk_check_launch("mixup_targets");
+}
+
+int vitk_copy_samples(const void* src, void* dst, const int* sample_list, int count, int64_t elems_per_sample, void* stream) {
+    VITK_REQUIRE(src && dst && sample_list && count > 0 && elems_per_sample > 0, "copy_samples: bad arguments");
+    VITK_REQUIRE(elems_per_sample % 8 == 0 && vitk_aligned(src, 16) && vitk_aligned(dst, 16),
+                 "copy_samples: bf16 elements per sample must be a multiple of 8, pointers 16-byte aligned");
+    const size_t per8 = (size_t)elems_per_sample / 8;
+    copy_samples_kernel<<<ew_grid((size_t)count * per8), EW_BLOCK, 0, (hipStream_t)stream>>>((const uint4*)src, (uint4*)dst, sample_list, count, per8);
+    return vitk_check_launch("copy_samples");
+}
+
+int vitk_rowscale_gather(const void* x, const float* rowscale, int rows_per_group, const int* sample_map, int nk, void* y, int D,
+                         void* stream) {
+    VITK_REQUIRE(x && rowscale && sample_map && y, "rowscale_gather: null pointer");
+    VITK_REQUIRE(nk > 0 && D > 0 && D % 8 == 0 && rows_per_group > 0, "rowscale_gather: bad shape");
+    VITK_REQUIRE(vitk_aligned(x, 16) && vitk_aligned(y, 16), "rowscale_gather: pointers must be 16-byte aligned");
+    rowscale_gather_kernel<<<ew_grid((size_t)nk * rows_per_group * D / 8), EW_BLOCK, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x, rowscale, rows_per_group, sample_map, nk, (bf16_t*)y, D);
+    return vitk_check_launch("rowscale_gather");
 }
 
 }  // extern "C"

@@ -35,6 +35,7 @@ struct GemmNTParams {
     const bf16_t* aux; int ldaux;
     const float* pos; int patches; int prefix;
     int tiles_n; int num_tiles;
+    const int* smap; int rps;     // BIAS_RES only: output / residual row of GEMM row m is smap[m / rps] * rps + m % rps
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Remap so that every XCD works on a
@@ -135,10 +136,10 @@ static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float 
         store_bf16<W>(p.out2 + (size_t)m * p.ldout2 + n, a);
     } else if (EPI == VITK_EPI_BIAS_RES) {
         float r[W];
-        if (side == nullptr) load_bf16<W>(p.res + (size_t)m * p.ldres + n, r);
+        if (side == nullptr) load_bf16<W>(p.res + (size_t)orow * p.ldres + n, r);
 #pragma unroll
         for (int j = 0; j < W; ++j) v[j] = (side ? side[j] : r[j]) + rs * v[j];
-        store_bf16<W>((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
+        store_bf16<W>((bf16_t*)p.C + (size_t)orow * p.ldc + n, v);
     } else if (EPI == VITK_EPI_PATCH) {
         add_f32<W>(posrow + n, v);
         store_bf16<W>((bf16_t*)p.C + (size_t)orow * p.ldc + n, v);
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTParams p) {
         const float* posrow = nullptr;
         if (EPI == VITK_EPI_BIAS_RES) {
             if (p.rowscale != nullptr) rs = p.rowscale[m / p.rows_per_group];
+            if (p.smap != nullptr) { const int c = m / p.rps; orow = p.smap[c] * p.rps + (m - c * p.rps); }
         }
         if (EPI == VITK_EPI_PATCH) {
             const int b = m / p.patches, pi = m - b * p.patches;
@@ -456,6 +458,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
             for (int i = 0; i < 8; ++i) {
                 int m = m0 + wm * 128 + (tm_base + (i >> 1)) * 16 + (i & 1) * 8 + srow;
                 m = m < p.M ? m : p.M - 1;
+                if (EPI == VITK_EPI_BIAS_RES && p.smap != nullptr) { const int c = m / p.rps; m = p.smap[c] * p.rps + (m - c * p.rps); }
                 const int n = ecol < p.N ? ecol : 0;
                 side[SIDE ? i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(nt_side_ptr<EPI>(p, m, n)));
             }
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
                     const float* posrow = nullptr;
                     if (EPI == VITK_EPI_BIAS_RES) {
                         if (p.rowscale != nullptr) rs = p.rowscale[m / p.rows_per_group];
+                        if (p.smap != nullptr) { const int c = m / p.rps; orow = p.smap[c] * p.rps + (m - c * p.rps); }
                     }
                     if (EPI == VITK_EPI_PATCH) {
                         const int b = m / p.patches, pi = m - b * p.patches;
@@ -940,9 +944,10 @@ static int vitk_num_cus() {
 
 extern "C" {
 
-int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
-                 const float* bias, const void* res, int ldres, const float* rowscale, int rows_per_group, void* out2,
-                 int ldout2, const void* aux, int ldaux, const float* pos, int patches, int prefix, void* stream) {
+static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
+                        const float* bias, const void* res, int ldres, const float* rowscale, int rows_per_group, void* out2,
+                        int ldout2, const void* aux, int ldaux, const float* pos, int patches, int prefix, const int* sample_map,
+                        int rows_per_sample, void* stream) {
     VITK_REQUIRE(A && B && C, "gemm_nt: null operand");
     VITK_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
     VITK_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K,
@@ -969,6 +974,7 @@ int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ld
     p.M = M; p.N = N; p.K = K; p.bias = bias; p.res = (const bf16_t*)res; p.ldres = ldres;
     p.rowscale = rowscale; p.rows_per_group = rows_per_group; p.out2 = (bf16_t*)out2; p.ldout2 = ldout2;
     p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pos = pos; p.patches = patches; p.prefix = prefix;
+    p.smap = sample_map; p.rps = rows_per_sample;
     hipStream_t s = (hipStream_t)stream;
     // large problems with K a multiple of 64 take the persistent 256x256 direct-to-LDS kernel; the 128x128 register-staged kernel
     // handles K tails (zero fill) and small shapes.  VITK_GEMM_SMALL=1 forces the latter (A/B testing).
@@ -1018,6 +1024,22 @@ int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ld
     }
     if (pr) vitk_prof_end(stream);
     return vitk_check_launch("gemm_nt");
+}
+
+int vitk_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
+                 const float* bias, const void* res, int ldres, const float* rowscale, int rows_per_group, void* out2,
+                 int ldout2, const void* aux, int ldaux, const float* pos, int patches, int prefix, void* stream) {
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, epilogue, bias, res, ldres, rowscale, rows_per_group, out2, ldout2, aux, ldaux,
+                        pos, patches, prefix, nullptr, 0, stream);
+}
+
+int vitk_gemm_nt_res_scatter(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                             const void* res, int ldres, const float* rowscale, int rows_per_group, const int* sample_map,
+                             int rows_per_sample, void* stream) {
+    VITK_REQUIRE(sample_map && rows_per_sample > 0 && M % rows_per_sample == 0,
+                 "gemm_nt_res_scatter: sample_map and rows_per_sample dividing M are required (M=%d rows_per_sample=%d)", M, rows_per_sample);
+    return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, VITK_EPI_BIAS_RES, bias, res, ldres, rowscale, rows_per_group, nullptr, 0, nullptr,
+                        0, nullptr, 0, 0, sample_map, rows_per_sample, stream);
 }
 
 size_t vitk_gemm_tn_workspace(int M, int N, int K) {

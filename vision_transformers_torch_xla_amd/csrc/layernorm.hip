@@ -23,13 +23,19 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
-                                                      float eps) {
+                                                      float eps, const int* __restrict__ smap, int rps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D >> 3;
     const float invD = 1.0f / (float)D;
     const int stride = gridDim.x * LN_ROWS_PER_BLOCK;
     int row = blockIdx.x * LN_ROWS_PER_BLOCK + wave;
     if (row >= M) return;
+    // with a sample map, output row r (compact) normalises input row smap[r / rps] * rps + r % rps
+    auto src_row = [&](int r) -> size_t {
+        if (smap == nullptr) return (size_t)r;
+        const int c = r / rps;
+        return (size_t)smap[c] * rps + (r - c * rps);
+    };
     int cc[NV];
     bool ok[NV];
 #pragma unroll
@@ -50,12 +56,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
         bt[i][0] = b0.x; bt[i][1] = b0.y; bt[i][2] = b0.z; bt[i][3] = b0.w; bt[i][4] = b1.x; bt[i][5] = b1.y; bt[i][6] = b1.z; bt[i][7] = b1.w;
     }
     ln_u4 cur[NV], nxt[NV];
+    {
+        const size_t sr = src_row(row);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) cur[i] = *reinterpret_cast<const ln_u4*>(x + (size_t)row * D + 8 * cc[i]);
+        for (int i = 0; i < NV; ++i) cur[i] = *reinterpret_cast<const ln_u4*>(x + sr * D + 8 * cc[i]);
+    }
     for (; row < M; row += stride) {
-        const int nrow = row + stride < M ? row + stride : row;
+        const size_t nsr = src_row(row + stride < M ? row + stride : row);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) nxt[i] = *reinterpret_cast<const ln_u4*>(x + (size_t)nrow * D + 8 * cc[i]);
+        for (int i = 0; i < NV; ++i) nxt[i] = *reinterpret_cast<const ln_u4*>(x + nsr * D + 8 * cc[i]);
         float v[NV][8];
         float s = 0.f;
 #pragma unroll
@@ -104,7 +113,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                       const float* __restrict__ gamma, const bf16_t* __restrict__ dres,
                                                       bf16_t* __restrict__ dx, const float* __restrict__ rowscale,
                                                       int rows_per_group, bf16_t* __restrict__ dxs,
-                                                      float* __restrict__ partial /*[grid][2][D]*/, int M, int D) {
+                                                      float* __restrict__ partial /*[grid][2][D]*/, int M, int D,
+                                                      const int* __restrict__ in_inv, const int* __restrict__ out_inv) {
     extern __shared__ __attribute__((aligned(16))) float ln_smem[];   // [4][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = D >> 3;
@@ -124,13 +134,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const int c = lane + 64 * i;
         cc[i] = c < nvec ? c : 0;        // lanes past the row re-read chunk 0 and ignore it
     }
+    // Sample maps (stochastic depth, rows_per_group rows per sample): dy, mean and rstd may be COMPACT over the samples that
+    // took the branch - in_inv[sample] is the sample's compact index, or -1 when it skipped the branch (then dx = dres) - and
+    // the scaled copy may be compact over the samples of the next branch (out_inv likewise).  x, dres and dx are full.
+    auto compact_row = [&](int r) -> int {          // row of dy / mean / rstd for full row r, -1: the sample skipped the branch
+        if (in_inv == nullptr) return r;
+        const int smp = r / rows_per_group;
+        const int c = in_inv[smp];
+        return c < 0 ? -1 : c * rows_per_group + (r - smp * rows_per_group);
+    };
     ln_u4 rx[NV], rd[NV], rr[NV], nx[NV], nd[NV], nr[NV];
+    int crow = -1, ncrow = -1;
     if (row < M) {
+        crow = compact_row(row);
+        const int cr = crow < 0 ? 0 : crow;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const size_t o = (size_t)row * D + 8 * cc[i];
             rx[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(x + o));
-            rd[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dy + o));
+            rd[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dy + (size_t)cr * D + 8 * cc[i]));
             if (RES) rr[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dres + o));
         }
     }
@@ -138,17 +160,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const size_t off = (size_t)row * D;
         {   // the next row's loads travel under this row's arithmetic (the last trip re-reads its own row)
             const int nrow = row + stride < M ? row + stride : row;
+            ncrow = compact_row(nrow);
+            const int cr = ncrow < 0 ? 0 : ncrow;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const size_t o = (size_t)nrow * D + 8 * cc[i];
                 nx[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(x + o));
-                nd[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dy + o));
+                nd[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dy + (size_t)cr * D + 8 * cc[i]));
                 if (RES) nr[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dres + o));
             }
         }
-        const float mu = mean[row], rs = rstd[row];
+        const bool took = crow >= 0;                 // wave-uniform
+        const int srow = took ? crow : 0;            // row of the statistics
+        const float mu = mean[srow], rs = rstd[srow];
         float sc = 1.0f;
-        if (SCALED) sc = rowscale[row / rows_per_group];
+        long long orow = row;                        // row of the scaled copy, -1: the sample skips the next branch
+        if (SCALED) {
+            const int smp = row / rows_per_group;
+            sc = rowscale[smp];
+            if (out_inv != nullptr) {
+                const int c = out_inv[smp];
+                orow = c < 0 ? -1 : (long long)c * rows_per_group + (row - smp * rows_per_group);
+            }
+        }
         float xh[NV][8], gd[NV][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -157,7 +191,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             float xv[8], dv[8];
             ln_unpack(rx[i], xv);
             ln_unpack(rd[i], dv);
-            const bool ok = c < nvec;
+            const bool ok = c < nvec && took;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float h = ok ? (xv[j] - mu) * rs : 0.f;
@@ -187,19 +221,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                     for (int j = 0; j < 8; ++j) o[j] += r[j];
                 }
                 store8(dx + off + 8 * c, o);
-                if (SCALED) {
+                if (SCALED && orow >= 0) {
                     // scale the bf16 value that was just stored, as a separate pass over dx would
                     const uint4 w = pack8_bf16(o);
                     float q[8];
                     ln_unpack((ln_u4){w.x, w.y, w.z, w.w}, q);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) q[j] *= sc;
-                    store8(dxs + off + 8 * c, q);
+                    store8(dxs + (size_t)orow * D + 8 * c, q);
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) { rx[i] = nx[i]; rd[i] = nd[i]; if (RES) rr[i] = nr[i]; }
+        crow = ncrow;
     }
     // fold the 4 waves
     float* sg = ln_smem + (size_t)wave * 2 * D;
@@ -249,21 +284,34 @@ static int ln_bwd_grid(int M) {
 
 extern "C" {
 
-int vitk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
-                       int D, float eps, void* stream) {
+static int ln_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int D, float eps,
+                       const int* sample_map, int rows_per_sample, void* stream) {
     VITK_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
     VITK_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 1024, "layernorm_fwd: need M>0, D%%8==0, D<=1024 (M=%d D=%d)", M, D);
     VITK_REQUIRE(vitk_aligned(x, 16) && vitk_aligned(y, 16) && vitk_aligned(gamma, 16) && vitk_aligned(beta, 16),
                  "layernorm_fwd: pointers must be 16-byte aligned");
+    VITK_REQUIRE(!sample_map || (rows_per_sample > 0 && M % rows_per_sample == 0),
+                 "layernorm_fwd: a sample map needs rows_per_sample > 0 dividing M (M=%d rows_per_sample=%d)", M, rows_per_sample);
     hipStream_t s = (hipStream_t)stream;
     const int grid = ln_grid(M);
     const bool pr = vitk_prof_begin(stream, 4.0 * (double)M * (double)D, VITK_PROF_LN_FWD);
     if (D <= 512)
-        ln_fwd_kernel<1><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+        ln_fwd_kernel<1><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps, sample_map, rows_per_sample);
     else
-        ln_fwd_kernel<2><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+        ln_fwd_kernel<2><<<grid, 256, 0, s>>>((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps, sample_map, rows_per_sample);
     if (pr) vitk_prof_end(stream);
     return vitk_check_launch("layernorm_fwd");
+}
+
+int vitk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
+                       int D, float eps, void* stream) {
+    return ln_fwd_impl(x, gamma, beta, y, mean, rstd, M, D, eps, nullptr, 0, stream);
+}
+
+int vitk_layernorm_fwd_gather(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
+                              int D, float eps, const int* sample_map, int rows_per_sample, void* stream) {
+    VITK_REQUIRE(sample_map, "layernorm_fwd_gather: sample_map is required");
+    return ln_fwd_impl(x, gamma, beta, y, mean, rstd, M, D, eps, sample_map, rows_per_sample, stream);
 }
 
 size_t vitk_layernorm_bwd_workspace(int M, int D) {
@@ -273,7 +321,8 @@ size_t vitk_layernorm_bwd_workspace(int M, int D) {
 
 static int ln_bwd_impl(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const void* dres,
                        void* dx, const float* rowscale, int rows_per_group, void* dxs, float* dgamma, float* dbeta, int accumulate,
-                       int M, int D, void* workspace, size_t workspace_bytes, void* stream) {
+                       int M, int D, void* workspace, size_t workspace_bytes, void* stream, const int* in_inv = nullptr,
+                       const int* out_inv = nullptr) {
     VITK_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
     VITK_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 1024, "layernorm_bwd: need M>0, D%%8==0, D<=1024 (M=%d D=%d)", M, D);
     VITK_REQUIRE(vitk_aligned(dy, 16) && vitk_aligned(x, 16) && vitk_aligned(dx, 16) && (!dres || vitk_aligned(dres, 16)),
@@ -290,7 +339,7 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* mean, const f
     float* partial = (float*)workspace;
 #define VITK_LN_BWD(NV, R, S)                                                                                                  \
     ln_bwd_kernel<NV, R, S><<<grid, 256, smem, s>>>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, \
-                                                    (bf16_t*)dx, rowscale, rows_per_group, (bf16_t*)dxs, partial, M, D)
+                                                    (bf16_t*)dx, rowscale, rows_per_group, (bf16_t*)dxs, partial, M, D, in_inv, out_inv)
     const int sel = (D <= 512 ? 0 : 4) + (dres ? 2 : 0) + (rowscale ? 1 : 0);
     const bool pr = vitk_prof_begin(stream, (6.0 + (dres ? 2.0 : 0.0) + (rowscale ? 2.0 : 0.0)) * (double)M * (double)D, VITK_PROF_LN_BWD);
     switch (sel) {
@@ -325,6 +374,18 @@ int vitk_layernorm_bwd_scaled(const void* dy, const void* x, const float* mean, 
     VITK_REQUIRE(rowscale && dx_scaled, "layernorm_bwd_scaled: rowscale and dx_scaled are required");
     return ln_bwd_impl(dy, x, mean, rstd, gamma, dres, dx, rowscale, rows_per_group, dx_scaled, dgamma, dbeta, accumulate, M, D,
                        workspace, workspace_bytes, stream);
+}
+
+int vitk_layernorm_bwd_gather(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                              const void* dres, void* dx, const float* rowscale, int rows_per_sample, void* dx_scaled,
+                              const int* in_inv, const int* out_inv, float* dgamma, float* dbeta, int accumulate, int M, int D,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    VITK_REQUIRE(rows_per_sample > 0 && M % rows_per_sample == 0, "layernorm_bwd_gather: rows_per_sample must divide M (M=%d, %d)", M,
+                 rows_per_sample);
+    VITK_REQUIRE(!rowscale == !dx_scaled, "layernorm_bwd_gather: rowscale and dx_scaled come together");
+    VITK_REQUIRE(!out_inv || rowscale, "layernorm_bwd_gather: out_inv needs rowscale / dx_scaled");
+    return ln_bwd_impl(dy, x, mean, rstd, gamma, dres, dx, rowscale, rows_per_sample, dx_scaled, dgamma, dbeta, accumulate, M, D,
+                       workspace, workspace_bytes, stream, in_inv, out_inv);
 }
 
 }  // extern "C"

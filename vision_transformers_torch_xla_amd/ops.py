@@ -49,22 +49,33 @@ _default_ws = Workspace()
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
-def layernorm_fwd(x, gamma, beta, eps=1e-6):
-    """x bf16 [M,D] -> (y bf16 [M,D], mean fp32 [M], rstd fp32 [M])"""
+def layernorm_fwd(x, gamma, beta, eps=1e-6, smap=None, rows_per_sample=0):
+    """x bf16 [M,D] -> (y bf16 [M,D], mean fp32 [M], rstd fp32 [M]).  With smap (int32 [nk], sample indices): the outputs are
+    compact over those samples, rows_per_sample rows each."""
     _chk(x, bf16, "x"); _chk(gamma, f32, "gamma"); _chk(beta, f32, "beta")
     M, D = x.shape
-    y = torch.empty_like(x)
+    lib = _lib.load()
+    if smap is not None:
+        _chk(smap, torch.int32, "smap")
+        M = smap.numel() * rows_per_sample
+    y = torch.empty((M, D), dtype=bf16, device=x.device)
     mean = torch.empty(M, dtype=f32, device=x.device)
     rstd = torch.empty(M, dtype=f32, device=x.device)
-    check(_lib.load().vitk_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), M, D, eps, _stream()),
-          "layernorm_fwd")
+    if smap is not None:
+        check(lib.vitk_layernorm_fwd_gather(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), M, D, eps, _ptr(smap),
+                                            int(rows_per_sample), _stream()), "layernorm_fwd_gather")
+    else:
+        check(lib.vitk_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), M, D, eps, _stream()),
+              "layernorm_fwd")
     return y, mean, rstd
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, accumulate=False, ws: Workspace = None, dx=None,
-                  rowscale=None, rows_per_group=0):
+                  rowscale=None, rows_per_group=0, in_inv=None, out_inv=None, out_rows=None):
     """Returns dx bf16 [M,D] (= LN backward of dy, plus dres when given); writes/accumulates dgamma, dbeta (fp32 [D]).
-    With rowscale (fp32 [M / rows_per_group]) returns (dx, dx_scaled) where dx_scaled[row] = rowscale[group] * dx[row]."""
+    With rowscale (fp32 [M / rows_per_group]) returns (dx, dx_scaled) where dx_scaled[row] = rowscale[group] * dx[row].
+    in_inv (int32 [samples]): dy / mean / rstd are compact, in_inv[sample] = compact index or -1 (sample skipped the branch);
+    out_inv: dx_scaled is compact over the samples with out_inv >= 0 (out_rows rows)."""
     _chk(dy, bf16, "dy"); _chk(x, bf16, "x"); _chk(gamma, f32, "gamma"); _chk(dgamma, f32, "dgamma"); _chk(dbeta, f32, "dbeta")
     if dres is not None:
         _chk(dres, bf16, "dres")
@@ -74,9 +85,19 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, accumulate
     w = (ws or _default_ws).get(need, x.device)
     if dx is None:
         dx = torch.empty_like(x)
+    dxs = None
     if rowscale is not None:
         _chk(rowscale, f32, "rowscale")
-        dxs = torch.empty_like(x)
+        dxs = torch.empty((M if out_inv is None else out_rows, D), dtype=bf16, device=x.device)
+    if in_inv is not None or out_inv is not None:
+        for t, n in ((in_inv, "in_inv"), (out_inv, "out_inv")):
+            if t is not None:
+                _chk(t, torch.int32, n)
+        check(lib.vitk_layernorm_bwd_gather(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres), _ptr(dx), _ptr(rowscale),
+                                            int(rows_per_group), _ptr(dxs), _ptr(in_inv), _ptr(out_inv), _ptr(dgamma), _ptr(dbeta),
+                                            int(accumulate), M, D, _ptr(w), w.numel(), _stream()), "layernorm_bwd_gather")
+        return (dx, dxs) if rowscale is not None else dx
+    if rowscale is not None:
         check(lib.vitk_layernorm_bwd_scaled(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres), _ptr(dx), _ptr(rowscale),
                                             int(rows_per_group), _ptr(dxs), _ptr(dgamma), _ptr(dbeta), int(accumulate), M, D, _ptr(w),
                                             w.numel(), _stream()), "layernorm_bwd_scaled")
@@ -88,7 +109,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, accumulate
 
 # ----------------------------------------------------------------------------------------------------- GEMM
 def gemm_nt(a, b, *, epilogue=EPI_PLAIN, bias=None, out=None, out_dtype=bf16, res=None, rowscale=None, rows_per_group=0,
-            out2=None, aux=None, pos=None, patches=0, prefix=0, out_rows=None):
+            out2=None, aux=None, pos=None, patches=0, prefix=0, out_rows=None, smap=None, rows_per_sample=0):
     """C[M,N] = a[M,K] @ b[N,K]^T with a fused epilogue (see vitk.h).  a, b bf16; 2-D, last dim contiguous."""
     for t, n in ((a, "a"), (b, "b")):
         if not t.is_cuda or t.dtype != bf16 or t.dim() != 2 or t.stride(1) != 1:
@@ -106,6 +127,14 @@ def gemm_nt(a, b, *, epilogue=EPI_PLAIN, bias=None, out=None, out_dtype=bf16, re
     ldres = res.stride(0) if res is not None else 0
     ldout2 = out2.stride(0) if out2 is not None else 0
     ldaux = aux.stride(0) if aux is not None else 0
+    if smap is not None:        # bias + residual with the rows scattered by sample (stochastic depth over the kept samples only)
+        if epilogue != EPI_BIAS_RES:
+            raise _lib.VitkError("gemm_nt: a sample map goes with the bias + residual epilogue only")
+        _chk(smap, torch.int32, "smap")
+        check(_lib.load().vitk_gemm_nt_res_scatter(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), ldc, M, N, K, _ptr(bias), _ptr(res),
+                                                   ldres, _ptr(rowscale), rows_per_group, _ptr(smap), int(rows_per_sample), _stream()),
+              "gemm_nt_res_scatter")
+        return out
     check(_lib.load().vitk_gemm_nt(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), ldc, M, N, K, epilogue, _ptr(bias),
                                    _ptr(res), ldres, _ptr(rowscale), rows_per_group, _ptr(out2), ldout2, _ptr(aux), ldaux,
                                    _ptr(pos), patches, prefix, _stream()), "gemm_nt")
@@ -216,6 +245,24 @@ def rowscale(x, scale, rows_per_group, out=None):
         out = torch.empty_like(x)
     check(_lib.load().vitk_rowscale(_ptr(x), _ptr(scale), rows_per_group, _ptr(out), M, D, _stream()), "rowscale")
     return out
+
+
+def rowscale_gather(x, scale, rows_per_group, smap):
+    """compact scaled copy: y[c*rpg + t] = scale[smap[c]] * x[smap[c]*rpg + t]"""
+    _chk(x, bf16, "x"); _chk(scale, f32, "scale"); _chk(smap, torch.int32, "smap")
+    nk, D = smap.numel(), x.shape[1]
+    out = torch.empty((nk * rows_per_group, D), dtype=bf16, device=x.device)
+    check(_lib.load().vitk_rowscale_gather(_ptr(x), _ptr(scale), rows_per_group, _ptr(smap), nk, _ptr(out), D, _stream()), "rowscale_gather")
+    return out
+
+
+def copy_samples(src, dst, sample_list, elems_per_sample):
+    """dst[s] = src[s] for the whole samples in sample_list (int32)"""
+    _chk(src, bf16, "src"); _chk(dst, bf16, "dst"); _chk(sample_list, torch.int32, "sample_list")
+    if sample_list.numel():
+        check(_lib.load().vitk_copy_samples(_ptr(src), _ptr(dst), _ptr(sample_list), sample_list.numel(), int(elems_per_sample), _stream()),
+              "copy_samples")
+    return dst
 
 
 def cast_f32_to_bf16(src, dst=None):

@@ -23,6 +23,7 @@ There is no CPU path: tensors must live on the GPU and libvitk.so must be built.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -94,6 +95,71 @@ class PatchEmbed(nn.Module):
         self.proj = _PatchProj(in_chans, dim, patch)
 
 
+class _Branch:
+    """Stochastic depth of ONE residual branch for one step.  `scale` (fp32 [B] on the GPU) is 0 for the samples that drop the
+    branch and 1/keep for the others.  timm's DropPath computes the branch for every sample and multiplies by that factor
+    (models/vision_transformer.py:161,173,176-177); here, when `compact` is set, the branch is computed for the kept samples
+    only - LayerNorm gathers their rows into a compact batch, the projection GEMM scatters its residual epilogue back, the
+    dropped samples' rows are copied - which gives the same activations and gradients (0 * branch = 0) for less work.
+    kept / dropped: int32 sample lists; inv[sample] = index in kept or -1; scale_c = scale[kept]."""
+    __slots__ = ("scale", "compact", "nk", "kept", "inv", "dropped", "scale_c")
+
+    @staticmethod
+    def from_masks(mask, keep, device, compact, ring):
+        """mask bool [R, B] and keep fp32 [R] on the host -> R branches; two host->device copies in all"""
+        R, B = mask.shape
+        nk = mask.sum(1).tolist()
+        order = torch.argsort((~mask).to(torch.int8), dim=1, stable=True).to(torch.int32)       # kept samples first, ascending
+        inv = torch.where(mask, torch.cumsum(mask, 1, dtype=torch.int32) - 1, torch.full((), -1, dtype=torch.int32))
+        scale = mask.to(f32) / keep[:, None]
+        ints, flts = ring.next(2 * R * B)
+        ints[:R * B].view(R, B).copy_(order); ints[R * B:].view(R, B).copy_(inv)
+        flts[:R * B].view(R, B).copy_(scale); flts[R * B:].view(R, B).copy_((1.0 / keep)[:, None].expand(R, B))
+        gi = ints.to(device, non_blocking=True)
+        gf = flts.to(device, non_blocking=True)
+        out = []
+        for r in range(R):
+            b = _Branch()
+            b.scale, b.nk = gf[r * B:(r + 1) * B], int(nk[r])
+            b.compact = bool(compact and b.nk < B)
+            b.kept = gi[r * B:r * B + b.nk]
+            b.dropped = gi[r * B + b.nk:(r + 1) * B]
+            b.inv = gi[(R + r) * B:(R + r + 1) * B]
+            b.scale_c = gf[(R + r) * B:(R + r) * B + b.nk]
+            out.append(b)
+        return out
+
+    @staticmethod
+    def from_scale(scale_cpu, device, compact):
+        """an explicit per-sample factor (tests): samples with factor 0 drop the branch"""
+        b = _Branch()
+        mask = scale_cpu != 0
+        B = scale_cpu.numel()
+        b.scale, b.nk = scale_cpu.to(device).contiguous(), int(mask.sum())
+        b.compact = bool(compact and b.nk < B)
+        order = torch.argsort((~mask).to(torch.int8), stable=True).to(torch.int32)
+        b.kept, b.dropped = order[:b.nk].to(device), order[b.nk:].to(device)
+        b.inv = torch.where(mask, torch.cumsum(mask, 0, dtype=torch.int32) - 1, torch.full((), -1, dtype=torch.int32)).to(device)
+        b.scale_c = scale_cpu[mask].to(device).contiguous()
+        return b
+
+
+class _PinRing:
+    """A few pinned host buffers reused round-robin for the per-step index tables (the host runs at most a step or two ahead of
+    the asynchronous copies that read them)."""
+
+    def __init__(self, slots=8):
+        self.slots, self.i, self.bufs = slots, 0, {}
+
+    def next(self, n):
+        key = (n, self.i % self.slots)
+        self.i += 1
+        if key not in self.bufs:
+            pin = torch.cuda.is_available()
+            self.bufs[key] = (torch.empty(n, dtype=torch.int32, pin_memory=pin), torch.empty(n, dtype=f32, pin_memory=pin))
+        return self.bufs[key]
+
+
 class _ViTFunction(torch.autograd.Function):
     """forward = all layers through libvitk, keeping what backward needs; backward fills the flat gradient buffer."""
 
@@ -163,6 +229,8 @@ class VisionTransformer(nn.Module):
         if distilled:
             self.head_dist = _Linear(embed_dim, num_classes)
         self._forced_drop_scales = None      # tests inject per-layer DropPath factors here
+        self._compact_droppath = os.environ.get("VITK_DROPPATH_COMPACT", "1") != "0"   # compute a branch for its kept samples only
+        self._pin_ring = _PinRing()
         self._bwd_taps = None                # tests: dict that receives per-layer intermediate gradients
         self._grad_ready_hook = None         # data-parallel reducer: called with the flat offset below which grads are final
         self._ws = ops.Workspace()
@@ -326,17 +394,23 @@ class VisionTransformer(nn.Module):
 
     # ---------------------------------------------------------------------------------------------- forward
     def _draw_drop_scales(self, B, device):
-        """DropPath (timm drop_path, scale_by_keep): per sample Bernoulli(keep)/keep, one draw per residual branch."""
+        """DropPath (timm drop_path, scale_by_keep): per sample Bernoulli(keep)/keep, one draw per residual branch.
+        Returns one (_Branch | None, _Branch | None) pair per block.  The draws are made on the HOST (torch's CPU generator, so
+        torch.manual_seed governs them) because the launch shapes depend on them: a branch is computed for the samples that
+        keep it only (see _Branch); all index tables of a step travel to the GPU in two asynchronous copies."""
         if self._forced_drop_scales is not None:
-            return [tuple(None if s is None else s.to(device=device, dtype=f32).contiguous() for s in pair)
-                    for pair in self._forced_drop_scales]
-        out = []
-        for blk in self.blocks:
-            if self.training and blk.drop_path > 0.0:
-                keep = 1.0 - blk.drop_path
-                out.append(tuple(torch.empty(B, dtype=f32, device=device).bernoulli_(keep).div_(keep) for _ in range(2)))
-            else:
-                out.append((None, None))
+            return [tuple(None if s is None else _Branch.from_scale(s.to(dtype=f32).cpu(), device, self._compact_droppath)
+                          for s in pair) for pair in self._forced_drop_scales]
+        rates = [blk.drop_path if self.training else 0.0 for blk in self.blocks]
+        active = [i for i, r in enumerate(rates) if r > 0.0]
+        out = [(None, None)] * self.depth
+        if not active:
+            return out
+        keep = torch.tensor([1.0 - rates[i] for i in active for _ in range(2)], dtype=f32)          # [2A]
+        mask = torch.rand(len(keep), B) < keep[:, None]
+        plans = _Branch.from_masks(mask, keep, device, self._compact_droppath, self._pin_ring)
+        for k, i in enumerate(active):
+            out[i] = (plans[2 * k], plans[2 * k + 1])
         return out
 
     def forward(self, x: torch.Tensor):
@@ -368,16 +442,43 @@ class VisionTransformer(nn.Module):
         for i, blk in enumerate(self.blocks):
             s1, s2 = scales[i]
             pre = f"blocks.{i}."
-            y1, m1, r1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
-            qkv = ops.gemm_nt(y1, wb[pre + "attn.qkv.weight"], epilogue=EPI_BIAS, bias=blk.attn.qkv.bias)
-            o, lse = ops.attention_fwd(qkv, B, N, H, scale)
-            x2 = ops.gemm_nt(o, wb[pre + "attn.proj.weight"], epilogue=EPI_BIAS_RES, bias=blk.attn.proj.bias, res=x,
-                             rowscale=s1, rows_per_group=N)
-            y2, m2, r2 = ops.layernorm_fwd(x2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-            a = torch.empty((M, blk.mlp.fc1.out_features), dtype=bf16, device=img.device)
-            h = ops.gemm_nt(y2, wb[pre + "mlp.fc1.weight"], epilogue=EPI_BIAS_GELU, bias=blk.mlp.fc1.bias, out2=a)
-            x3 = ops.gemm_nt(a, wb[pre + "mlp.fc2.weight"], epilogue=EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x2,
-                             rowscale=s2, rows_per_group=N)
+            # ---- attention branch: x2 = x + s1 * proj(attn(qkv(ln1(x))))
+            if s1 is not None and s1.compact and s1.nk == 0:
+                y1 = m1 = r1 = qkv = o = lse = None
+                x2 = x                                              # every sample drops the branch
+            else:
+                c1 = s1 is not None and s1.compact
+                nb = s1.nk if c1 else B
+                y1, m1, r1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, smap=s1.kept if c1 else None,
+                                               rows_per_sample=N)
+                qkv = ops.gemm_nt(y1, wb[pre + "attn.qkv.weight"], epilogue=EPI_BIAS, bias=blk.attn.qkv.bias)
+                o, lse = ops.attention_fwd(qkv, nb, N, H, scale)
+                if c1:
+                    x2 = torch.empty_like(x)
+                    ops.gemm_nt(o, wb[pre + "attn.proj.weight"], epilogue=EPI_BIAS_RES, bias=blk.attn.proj.bias, res=x, rowscale=s1.scale_c,
+                                rows_per_group=N, out=x2, smap=s1.kept, rows_per_sample=N)
+                    ops.copy_samples(x, x2, s1.dropped, N * D)
+                else:
+                    x2 = ops.gemm_nt(o, wb[pre + "attn.proj.weight"], epilogue=EPI_BIAS_RES, bias=blk.attn.proj.bias, res=x,
+                                     rowscale=None if s1 is None else s1.scale, rows_per_group=N)
+            # ---- MLP branch: x3 = x2 + s2 * fc2(gelu(fc1(ln2(x2))))
+            if s2 is not None and s2.compact and s2.nk == 0:
+                y2 = m2 = r2 = h = a = None
+                x3 = x2
+            else:
+                c2 = s2 is not None and s2.compact
+                y2, m2, r2 = ops.layernorm_fwd(x2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, smap=s2.kept if c2 else None,
+                                               rows_per_sample=N)
+                a = torch.empty((y2.shape[0], blk.mlp.fc1.out_features), dtype=bf16, device=img.device)
+                h = ops.gemm_nt(y2, wb[pre + "mlp.fc1.weight"], epilogue=EPI_BIAS_GELU, bias=blk.mlp.fc1.bias, out2=a)
+                if c2:
+                    x3 = torch.empty_like(x2)
+                    ops.gemm_nt(a, wb[pre + "mlp.fc2.weight"], epilogue=EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x2, rowscale=s2.scale_c,
+                                rows_per_group=N, out=x3, smap=s2.kept, rows_per_sample=N)
+                    ops.copy_samples(x2, x3, s2.dropped, N * D)
+                else:
+                    x3 = ops.gemm_nt(a, wb[pre + "mlp.fc2.weight"], epilogue=EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x2,
+                                     rowscale=None if s2 is None else s2.scale, rows_per_group=N)
             if save:
                 layers.append((x, m1, r1, y1, qkv, o, lse, x2, m2, r2, y2, h, a, s1, s2))
             x = x3
@@ -454,7 +555,43 @@ class VisionTransformer(nn.Module):
             hook(self._head_end, False)
 
         layers = saved["layers"]
-        dout_mlp = None      # s2 * dx of the block about to be processed, when the LayerNorm backward below it already wrote it
+
+        def zero_branch(names):
+            if not acc:
+                for n in names:
+                    g[n].zero_()
+
+        def ln_bwd(dy, xin, mean, rstd, norm, gname, dres, took, nxt):
+            """LayerNorm backward + residual gradient; `took` = the branch this LayerNorm feeds (its dy may be compact),
+            `nxt` = the branch whose scaled input gradient this kernel also writes (None: no stochastic depth there)."""
+            kw = {}
+            if took is not None and took.compact:
+                kw["in_inv"] = took.inv
+            if nxt is not None:
+                kw.update(rowscale=nxt.scale, rows_per_group=N)
+                if nxt.compact:
+                    if nxt.nk == 0:
+                        kw.pop("rowscale")
+                    else:
+                        kw.update(out_inv=nxt.inv, out_rows=nxt.nk * N)
+            if "in_inv" in kw and "rows_per_group" not in kw:
+                kw["rows_per_group"] = N
+            r = ops.layernorm_bwd(dy, xin, mean, rstd, norm.weight, g[gname + ".weight"], g[gname + ".bias"], dres=dres, accumulate=acc,
+                                  ws=ws, **kw)
+            return r if isinstance(r, tuple) else (r, None)
+
+        def branch_input_grad(dx_full, br, prepared):
+            """the gradient that enters a branch: s * dx, compact when the branch is; `prepared` = the copy the LayerNorm backward
+            above already wrote"""
+            if br is None:
+                return dx_full
+            if prepared is not None:
+                return prepared
+            if br.compact:
+                return ops.rowscale_gather(dx_full, br.scale, N, br.kept)
+            return ops.rowscale(dx_full, br.scale, N)
+
+        dout_next = None     # s * dx for the branch about to be processed, when a LayerNorm backward already wrote it
         for i in reversed(range(self.depth)):
             blk = self.blocks[i]
             pre = f"blocks.{i}."
@@ -462,29 +599,35 @@ class VisionTransformer(nn.Module):
             layers[i] = None
             dx_in = dx
             # ---- MLP branch: x3 = x2 + s2 * fc2(gelu(fc1(ln2(x2))))
-            dout = dx if s2 is None else (dout_mlp if dout_mlp is not None else ops.rowscale(dx, s2, N))
-            dout_mlp = None
-            ops.gemm_tn(dout, a, g[pre + "mlp.fc2.weight"], dbias=g[pre + "mlp.fc2.bias"], accumulate=acc, ws=ws)
-            dh = ops.gemm_nt(dout, wt[pre + "mlp.fc2.weight"], epilogue=EPI_DGELU, aux=h)
-            ops.gemm_tn(dh, y2, g[pre + "mlp.fc1.weight"], dbias=g[pre + "mlp.fc1.bias"], accumulate=acc, ws=ws)
-            dy2 = ops.gemm_nt(dh, wt[pre + "mlp.fc1.weight"])
-            del dh
-            # the LayerNorm backward also writes the stochastic-depth-scaled copy its consumer needs (s1 * dx2 here)
-            dx2 = ops.layernorm_bwd(dy2, x2, m2, r2, blk.norm2.weight, g[pre + "norm2.weight"], g[pre + "norm2.bias"], dres=dx,
-                                    accumulate=acc, ws=ws, rowscale=s1, rows_per_group=N)
+            if s2 is not None and s2.compact and s2.nk == 0:
+                zero_branch([pre + n for n in ("mlp.fc2.weight", "mlp.fc2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "norm2.weight", "norm2.bias")])
+                dx2 = dx
+                dout_attn = None
+            else:
+                dout = branch_input_grad(dx, s2, dout_next)
+                ops.gemm_tn(dout, a, g[pre + "mlp.fc2.weight"], dbias=g[pre + "mlp.fc2.bias"], accumulate=acc, ws=ws)
+                dh = ops.gemm_nt(dout, wt[pre + "mlp.fc2.weight"], epilogue=EPI_DGELU, aux=h)
+                ops.gemm_tn(dh, y2, g[pre + "mlp.fc1.weight"], dbias=g[pre + "mlp.fc1.bias"], accumulate=acc, ws=ws)
+                dy2 = ops.gemm_nt(dh, wt[pre + "mlp.fc1.weight"])
+                del dh
+                # the LayerNorm backward also writes the stochastic-depth-scaled copy its consumer needs (s1 * dx2 here)
+                dx2, dout_attn = ln_bwd(dy2, x2, m2, r2, blk.norm2, pre + "norm2", dx, s2, s1)
+            dout_next = None
             # ---- attention branch: x2 = x + s1 * proj(attn(qkv(ln1(x))))
-            dx2, dout = dx2 if s1 is not None else (dx2, dx2)
-            ops.gemm_tn(dout, o, g[pre + "attn.proj.weight"], dbias=g[pre + "attn.proj.bias"], accumulate=acc, ws=ws)
-            do = ops.gemm_nt(dout, wt[pre + "attn.proj.weight"])
-            dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, scale, ws=ws)
-            ops.gemm_tn(dqkv, y1, g[pre + "attn.qkv.weight"], dbias=g[pre + "attn.qkv.bias"], accumulate=acc, ws=ws)
-            dy1 = ops.gemm_nt(dqkv, wt[pre + "attn.qkv.weight"])
-            del dqkv
-            s2_below = layers[i - 1][14] if i > 0 else None       # s2 of the next block to be processed
-            dx = ops.layernorm_bwd(dy1, x, m1, r1, blk.norm1.weight, g[pre + "norm1.weight"], g[pre + "norm1.bias"], dres=dx2,
-                                   accumulate=acc, ws=ws, rowscale=s2_below, rows_per_group=N)
-            if s2_below is not None:
-                dx, dout_mlp = dx
+            s2_below = layers[i - 1][14] if i > 0 else None       # the branch processed next
+            if s1 is not None and s1.compact and s1.nk == 0:
+                zero_branch([pre + n for n in ("attn.proj.weight", "attn.proj.bias", "attn.qkv.weight", "attn.qkv.bias", "norm1.weight", "norm1.bias")])
+                dx = dx2
+            else:
+                dout = branch_input_grad(dx2, s1, dout_attn)
+                nb = s1.nk if (s1 is not None and s1.compact) else B
+                ops.gemm_tn(dout, o, g[pre + "attn.proj.weight"], dbias=g[pre + "attn.proj.bias"], accumulate=acc, ws=ws)
+                do = ops.gemm_nt(dout, wt[pre + "attn.proj.weight"])
+                dqkv = ops.attention_bwd(qkv, o, do, lse, nb, N, H, scale, ws=ws)
+                ops.gemm_tn(dqkv, y1, g[pre + "attn.qkv.weight"], dbias=g[pre + "attn.qkv.bias"], accumulate=acc, ws=ws)
+                dy1 = ops.gemm_nt(dqkv, wt[pre + "attn.qkv.weight"])
+                del dqkv
+                dx, dout_next = ln_bwd(dy1, x, m1, r1, blk.norm1, pre + "norm1", dx2, s1, s2_below)
             if self._bwd_taps is not None:       # tests: the gradients entering / between / leaving the two half-blocks
                 self._bwd_taps[i] = dict(dx_in=dx_in, dx2=dx2, dx=dx, x=x, x2=x2)
             if hook is not None:
