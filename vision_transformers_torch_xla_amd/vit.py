@@ -117,6 +117,7 @@ class _Branch:
         flts[:R * B].view(R, B).copy_(scale); flts[R * B:].view(R, B).copy_((1.0 / keep)[:, None].expand(R, B))
         gi = ints.to(device, non_blocking=True)
         gf = flts.to(device, non_blocking=True)
+        ring.copied()
         out = []
         for r in range(R):
             b = _Branch()
@@ -145,11 +146,12 @@ class _Branch:
 
 
 class _PinRing:
-    """A few pinned host buffers reused round-robin for the per-step index tables (the host runs at most a step or two ahead of
-    the asynchronous copies that read them)."""
+    """A few pinned host buffers reused round-robin for the per-step index tables.  The copies that read them are asynchronous
+    and the host may run steps ahead of the GPU, so a slot is reused only after the event recorded behind its copies has
+    completed (a host-side wait that only triggers when the host is a whole ring ahead)."""
 
     def __init__(self, slots=8):
-        self.slots, self.i, self.bufs = slots, 0, {}
+        self.slots, self.i, self.bufs, self.events, self.last = slots, 0, {}, {}, None
 
     def next(self, n):
         key = (n, self.i % self.slots)
@@ -157,7 +159,19 @@ class _PinRing:
         if key not in self.bufs:
             pin = torch.cuda.is_available()
             self.bufs[key] = (torch.empty(n, dtype=torch.int32, pin_memory=pin), torch.empty(n, dtype=f32, pin_memory=pin))
+        ev = self.events.get(key)
+        if ev is not None:
+            ev.synchronize()
+        self.last = key
         return self.bufs[key]
+
+    def copied(self):
+        """call after the copies out of the slot handed out last have been enqueued"""
+        if torch.cuda.is_available() and self.last is not None:
+            ev = self.events.get(self.last)
+            if ev is None:
+                ev = self.events[self.last] = torch.cuda.Event()
+            ev.record()
 
 
 class _ViTFunction(torch.autograd.Function):
