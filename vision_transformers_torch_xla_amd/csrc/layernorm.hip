@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
                                                       const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
                                                       float eps, const int* __restrict__ smap, int rps) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row indices and map lookups stay scalar
     const int nvec = D >> 3;
     const float invD = 1.0f / (float)D;
     const int stride = gridDim.x * LN_ROWS_PER_BLOCK;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                       float* __restrict__ partial /*[grid][2][D]*/, int M, int D,
                                                       const int* __restrict__ in_inv, const int* __restrict__ out_inv) {
     extern __shared__ __attribute__((aligned(16))) float ln_smem[];   // [4][2][D]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row indices and map lookups stay scalar
     const int nvec = D >> 3;
     const float invD = 1.0f / (float)D;
     float g[NV][8], dg[NV][8], db[NV][8];
@@ -143,10 +143,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const int c = in_inv[smp];
         return c < 0 ? -1 : c * rows_per_group + (r - smp * rows_per_group);
     };
+    // Per-row scalars (statistics, branch scale, row of the scaled copy) are fetched one row ahead and the compact row
+    // index two rows ahead, so that no map or statistics load sits between a row's vector loads and its arithmetic.
+    struct RowMeta { float mu, rs, sc; long long orow; };
+    auto row_meta = [&](int r, int cr) -> RowMeta {
+        RowMeta m;
+        const int srow = cr < 0 ? 0 : cr;            // row of the statistics
+        m.mu = mean[srow]; m.rs = rstd[srow];
+        m.sc = 1.0f;
+        m.orow = r;                                  // row of the scaled copy, -1: the sample skips the next branch
+        if (SCALED) {
+            const int smp = r / rows_per_group;
+            m.sc = rowscale[smp];
+            if (out_inv != nullptr) {
+                const int c = out_inv[smp];
+                m.orow = c < 0 ? -1 : (long long)c * rows_per_group + (r - smp * rows_per_group);
+            }
+        }
+        return m;
+    };
+    auto clamp_row = [&](int r) -> int { return r < M ? r : (M - 1); };
     ln_u4 rx[NV], rd[NV], rr[NV], nx[NV], nd[NV], nr[NV];
-    int crow = -1, ncrow = -1;
+    int crow = -1, ncrow = -1, nncrow = -1;
+    RowMeta meta = {0.f, 0.f, 1.f, -1}, nmeta = meta;
     if (row < M) {
         crow = compact_row(row);
+        ncrow = compact_row(clamp_row(row + stride));
+        meta = row_meta(row, crow);
         const int cr = crow < 0 ? 0 : crow;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const size_t off = (size_t)row * D;
         {   // the next row's loads travel under this row's arithmetic (the last trip re-reads its own row)
             const int nrow = row + stride < M ? row + stride : row;
-            ncrow = compact_row(nrow);
+            if (row + stride >= M) ncrow = crow;
             const int cr = ncrow < 0 ? 0 : ncrow;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -169,20 +192,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 nd[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dy + (size_t)cr * D + 8 * cc[i]));
                 if (RES) nr[i] = __builtin_nontemporal_load(reinterpret_cast<const ln_u4*>(dres + o));
             }
+            nmeta = row_meta(nrow, ncrow);
+            nncrow = compact_row(clamp_row(row + 2 * stride));
         }
         const bool took = crow >= 0;                 // wave-uniform
-        const int srow = took ? crow : 0;            // row of the statistics
-        const float mu = mean[srow], rs = rstd[srow];
-        float sc = 1.0f;
-        long long orow = row;                        // row of the scaled copy, -1: the sample skips the next branch
-        if (SCALED) {
-            const int smp = row / rows_per_group;
-            sc = rowscale[smp];
-            if (out_inv != nullptr) {
-                const int c = out_inv[smp];
-                orow = c < 0 ? -1 : (long long)c * rows_per_group + (row - smp * rows_per_group);
-            }
-        }
+        const float mu = meta.mu, rs = meta.rs, sc = meta.sc;
+        const long long orow = meta.orow;
         float xh[NV][8], gd[NV][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) { rx[i] = nx[i]; rd[i] = nd[i]; if (RES) rr[i] = nr[i]; }
-        crow = ncrow;
+        crow = ncrow; ncrow = nncrow; meta = nmeta;
     }
     // fold the 4 waves
     float* sg = ln_smem + (size_t)wave * 2 * D;
