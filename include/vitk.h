@@ -167,6 +167,16 @@ int vitk_transpose_bf16(const void* src, void* dst, int rows, int cols, void* st
 int vitk_transpose_bf16_batched(const void* desc, int n, int total_tiles, void* stream);
 int vitk_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 
+/* ---- device tail of the input pipeline: src = B decoded images in host layout [B, src_h, src_w, 3] (uint8 when src_is_u8,
+ * else fp32), already on the device; dst = fp32 NCHW [B, 3, H, W], the window of H x W pixels at (top, left) of every image.
+ * Per element, each step rounded on its own: flip_lr for the samples with flip[b] != 0 (flip: device uint8 [B] or NULL;
+ * big_vision/pp/ops_image.py:69-82), value_range(vmin, vmax) = float(u)/255 for integers, then v*(vmax-vmin)+vmin
+ * (big_vision/pp/ops_general.py:26-43), HWC -> CHW (datasets.py:301-307) and, when mean3/std3 (HOST arrays of 3 floats, or
+ * both NULL) are given, (v - mean[c]) / std[c] (datasets.py:249-252).  W must be a multiple of 4. */
+int vitk_preprocess_images(const void* src, int src_is_u8, const unsigned char* flip, float* dst, int B, int H, int W,
+                           int src_h, int src_w, int top, int left, float vmin, float vmax, const float* mean3,
+                           const float* std3, void* stream);
+
 /* ---- mixup / cutmix in 'batch' mode on the device, in place on the fp32 NCHW batch x [B, per_sample]; sample b is paired
  * with sample B-1-b (x.flip(0)); B must be even.  Replaces timm.data.Mixup.__call__ as the reference applies it before
  * every training step (main.py:622-629, engine.py:132-133, 259-260).

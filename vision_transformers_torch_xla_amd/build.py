@@ -14,7 +14,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libvitk.so"
-SOURCES = ["api.hip", "layernorm.hip", "gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "optim.hip"]
+SOURCES = ["api.hip", "layernorm.hip", "gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "optim.hip", "preprocess.hip"]
 HEADERS = [CSRC / "common.h", CSRC.parent.parent / "include" / "vitk.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

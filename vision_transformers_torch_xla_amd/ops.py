@@ -436,3 +436,35 @@ def mixup_targets(target, num_classes: int, lam: float, on_value: float, off_val
     check(_lib.load().vitk_mixup_targets(_ptr(target), _ptr(out), num_classes, B, num_classes, float(lam), float(1. - lam),
                                          float(on_value), float(off_value), _stream()), "mixup_targets")
     return out
+
+
+# ------------------------------------------------------------------------------------------ input pipeline tail
+def preprocess_images(src, flip=None, out=None, window=None, value_range=(0.0, 1.0), mean=None, std=None):
+    """src uint8 / fp32 [B, Hs, Ws, 3] on the GPU -> fp32 NCHW [B, 3, H, W]: flip_lr for flip[b] != 0 (uint8 [B]), value_range,
+    HWC -> CHW, (v - mean) / std; window = (top, left, H, W) crops every image (default: the whole image)."""
+    import ctypes
+    if src.dtype not in (torch.uint8, f32):
+        raise _lib.VitkError(f"src: expected uint8 or float32 images, got {src.dtype}")
+    _chk(src, src.dtype, "src")
+    if src.dim() != 4 or src.shape[3] != 3:
+        raise _lib.VitkError(f"src: expected [B, H, W, 3], got {tuple(src.shape)}")
+    B, Hs, Ws, _ = src.shape
+    top, left, H, W = window if window is not None else (0, 0, Hs, Ws)
+    if flip is not None:
+        _chk(flip, torch.uint8, "flip")
+        if flip.numel() != B:
+            raise _lib.VitkError(f"flip: expected {B} flags, got {flip.numel()}")
+    if out is None:
+        out = torch.empty((B, 3, H, W), dtype=f32, device=src.device)
+    else:
+        _chk(out, f32, "out")
+        if tuple(out.shape) != (B, 3, H, W):
+            raise _lib.VitkError(f"out: expected {(B, 3, H, W)}, got {tuple(out.shape)}")
+    if (mean is None) != (std is None):
+        raise _lib.VitkError("mean and std go together")
+    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    s = (ctypes.c_float * 3)(*std) if std is not None else None
+    check(_lib.load().vitk_preprocess_images(_ptr(src), int(src.dtype == torch.uint8), _ptr(flip), _ptr(out), B, int(H), int(W), Hs, Ws,
+                                             int(top), int(left), float(value_range[0]), float(value_range[1]), m, s, _stream()),
+          "preprocess_images")
+    return out
