@@ -200,6 +200,9 @@ def main():
                 "also": {"kernel": "gemm_tnb_kernel / gemm_tn_kernel (weight gradients)", "achieved": round(tn_fl / (tn_ms * 1e-3) / 1e12, 1) if tn_ms > 0 else 0.0,
                          "launches": tn_n, "avg_launch_ms": round(tn_ms / max(tn_n, 1), 4)},
                 "sampled_steps": len(range(0, args.steps, args.prof_every)),
+                # a bracketed launch is timed with the chip to itself: in the sampled steps the weight-gradient GEMMs stay on the
+                # launch stream; in all other steps they overlap the data-gradient chain from a side stream
+                "sampling": "sampled steps run every kernel on one stream",
                 "gemm_share_of_step": round((nt_ms + tn_ms) / (elapsed * 1e3 * len(range(0, args.steps, args.prof_every)) / args.steps), 3),
             }
             # the HBM-bound kernels of the step, same event brackets: algorithmic bytes / launch time against the 8 TB/s peak

@@ -39,6 +39,7 @@ class GradReducer:
         self._works = []
         self._stream = None
         self._events = []
+        self._after = None        # latest event of a stream other than the current one that also writes gradients
         self.launched = []        # (start, end) slices reduced in the current backward, for tests / introspection
 
     def _side_stream(self, device):
@@ -46,18 +47,23 @@ class GradReducer:
             self._stream = torch.cuda.Stream(device=device)
         return self._stream
 
-    def ready(self, upto: int, final: bool):
-        """Backward reports that gradients in [0, upto) are final.  Reduce [done, upto) once it is a bucket's worth
-        (or at the end)."""
+    def ready(self, upto: int, final: bool, after=None):
+        """Backward reports that gradients in [0, upto) are final once everything queued on the current stream has run - and,
+        when backward writes some gradients on another stream, once `after` (an event recorded on that stream; later events
+        supersede earlier ones) has completed.  Reduce [done, upto) once it is a bucket's worth (or at the end)."""
         if not self.enabled or self._skip:
             if final:
                 self._done = 0
+                self._after = None
             return
+        if after is not None:
+            self._after = after
         if final or upto - self._done >= self.bucket_elems:
             self._launch(self._done, upto)
             self._done = upto
         if final:
             self._done = 0
+            self._after = None
 
     def _launch(self, a, b):
         if b <= a:
@@ -75,6 +81,8 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(cur)                      # the slice is complete once everything queued so far has run
             side.wait_event(ev)
+            if self._after is not None:
+                side.wait_event(self._after)
             with torch.cuda.stream(side):
                 if native_avg:
                     dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg)

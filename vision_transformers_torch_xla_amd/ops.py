@@ -392,8 +392,17 @@ def clip_grad_scale(g, sumsq_t, max_norm):
     check(_lib.load().vitk_clip_grad_scale(_ptr(g), g.numel(), _ptr(sumsq_t), float(max_norm), _stream()), "clip_grad_scale")
 
 
+_prof_on = False
+
+
 def prof_enable(on: bool):
+    global _prof_on
     check(_lib.load().vitk_prof_enable(int(on)), "prof_enable")
+    _prof_on = bool(on)
+
+
+def prof_enabled() -> bool:
+    return _prof_on
 
 
 PROF_ALL, PROF_GEMM_NT, PROF_GEMM_TN, PROF_LN_FWD, PROF_LN_BWD, PROF_ATTN_FWD, PROF_ATTN_BWD, PROF_ADAMW = -1, 0, 1, 2, 3, 4, 5, 6

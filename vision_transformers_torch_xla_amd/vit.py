@@ -524,6 +524,17 @@ class VisionTransformer(nn.Module):
         return outs, saved
 
     # --------------------------------------------------------------------------------------------- backward
+    def _wgrad_stream(self):
+        """side stream of the weight-gradient GEMMs (VITK_WGRAD_STREAM=0 turns it off), None: everything on the current stream"""
+        if os.environ.get("VITK_WGRAD_STREAM", "1") == "0":
+            return None
+        if ops.prof_enabled():       # an event-bracketed launch is timed with the chip to itself
+            return None
+        if getattr(self, "_wgrad_side", None) is None:
+            self._wgrad_side = torch.cuda.Stream(priority=int(os.environ.get("VITK_WGRAD_PRIO", "-1")))
+            self._ws_side = ops.Workspace()
+        return self._wgrad_side
+
     def _backward_impl(self, saved, douts):
         B = saved["B"]
         N, D, npre = self.num_tokens, self.embed_dim, self.num_prefix_tokens
@@ -605,6 +616,37 @@ class VisionTransformer(nn.Module):
                 return ops.rowscale_gather(dx_full, br.scale, N, br.kept)
             return ops.rowscale(dx_full, br.scale, N)
 
+        # Weight-gradient GEMMs have no consumer inside backward: on a side stream they fill the compute units that the tile
+        # rounds of the data-gradient GEMMs leave idle.  Their operands are kept from the allocator until the side stream is done.
+        side = self._wgrad_stream()
+
+        def wgrad(dy, xin, wname, bname):
+            if side is None:
+                ops.gemm_tn(dy, xin, g[wname], dbias=g[bname], accumulate=acc, ws=ws)
+                return
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                ops.gemm_tn(dy, xin, g[wname], dbias=g[bname], accumulate=acc, ws=self._ws_side)
+            dy.record_stream(side)
+            xin.record_stream(side)
+
+        def side_event():
+            if side is None:
+                return None
+            ev = torch.cuda.Event()
+            ev.record(side)
+            return ev
+
+        def report(upto, final):
+            if hook is not None:
+                ev = side_event()
+                if ev is None:
+                    hook(upto, final)
+                else:
+                    hook(upto, final, after=ev)     # the reduction waits for the side stream; this stream does not
+
         dout_next = None     # s * dx for the branch about to be processed, when a LayerNorm backward already wrote it
         for i in reversed(range(self.depth)):
             blk = self.blocks[i]
@@ -619,9 +661,9 @@ class VisionTransformer(nn.Module):
                 dout_attn = None
             else:
                 dout = branch_input_grad(dx, s2, dout_next)
-                ops.gemm_tn(dout, a, g[pre + "mlp.fc2.weight"], dbias=g[pre + "mlp.fc2.bias"], accumulate=acc, ws=ws)
+                wgrad(dout, a, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias")
                 dh = ops.gemm_nt(dout, wt[pre + "mlp.fc2.weight"], epilogue=EPI_DGELU, aux=h)
-                ops.gemm_tn(dh, y2, g[pre + "mlp.fc1.weight"], dbias=g[pre + "mlp.fc1.bias"], accumulate=acc, ws=ws)
+                wgrad(dh, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
                 dy2 = ops.gemm_nt(dh, wt[pre + "mlp.fc1.weight"])
                 del dh
                 # the LayerNorm backward also writes the stochastic-depth-scaled copy its consumer needs (s1 * dx2 here)
@@ -635,17 +677,16 @@ class VisionTransformer(nn.Module):
             else:
                 dout = branch_input_grad(dx2, s1, dout_attn)
                 nb = s1.nk if (s1 is not None and s1.compact) else B
-                ops.gemm_tn(dout, o, g[pre + "attn.proj.weight"], dbias=g[pre + "attn.proj.bias"], accumulate=acc, ws=ws)
+                wgrad(dout, o, pre + "attn.proj.weight", pre + "attn.proj.bias")
                 do = ops.gemm_nt(dout, wt[pre + "attn.proj.weight"])
                 dqkv = ops.attention_bwd(qkv, o, do, lse, nb, N, H, scale, ws=ws)
-                ops.gemm_tn(dqkv, y1, g[pre + "attn.qkv.weight"], dbias=g[pre + "attn.qkv.bias"], accumulate=acc, ws=ws)
+                wgrad(dqkv, y1, pre + "attn.qkv.weight", pre + "attn.qkv.bias")
                 dy1 = ops.gemm_nt(dqkv, wt[pre + "attn.qkv.weight"])
                 del dqkv
                 dx, dout_next = ln_bwd(dy1, x, m1, r1, blk.norm1, pre + "norm1", dx2, s1, s2_below)
             if self._bwd_taps is not None:       # tests: the gradients entering / between / leaving the two half-blocks
                 self._bwd_taps[i] = dict(dx_in=dx_in, dx2=dx2, dx=dx, x=x, x2=x2)
-            if hook is not None:
-                hook(self._layer_end[i], False)
+            report(self._layer_end[i], False)
 
         # ---- embedding: x0[b, t] = (t < prefix ? token_t : patches @ Wp^T + bp) + pos[t]
         ops.pos_tokens_bwd(dx, self._gpos2d, self._gtokens, B, N, D, npre, accumulate=acc)
@@ -656,8 +697,10 @@ class VisionTransformer(nn.Module):
             if p.grad is None or p.grad.data_ptr() != self._gview[n].data_ptr():
                 p.grad = self._gview[n]
         self._grad_valid = True
-        if hook is not None:
-            hook(self._total, True)
+        report(self._total, True)
+        ev = side_event()
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)      # the optimizer step reads every gradient
 
 
 # ------------------------------------------------------------------------------------------------- registry
