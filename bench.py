@@ -148,7 +148,7 @@ def main():
                                           num_training_steps_per_epoch=nsteps, update_freq=1, log_freq=10)
 
     run(args.warmup, 0)
-    want_roof = not args.no_roofline
+    want_roof = not args.no_roofline and args.prof_every > 0
     if want_roof:
         ops.prof_reset()
     if world > 1:

@@ -1,6 +1,9 @@
 #!/bin/bash
 # rocprofv3 kernel trace of bench.py (ViT-B/16 224) and of the 384-px workload; CSV stats land under gpurun_out/<tag>/
+# Per-kernel durations are only meaningful when launches do not share the chip, so the weight-gradient side stream is
+# switched off here (bench.py does the same in its event-bracketed steps); tools/gpu_trace.sh looks at the overlapped run.
 set -o pipefail
+export VITK_WGRAD_STREAM=0
 tag=${1:-prof}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
