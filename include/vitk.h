@@ -152,6 +152,10 @@ int vitk_slice_tokens(const void* x, void* y, int B, int N, int D, int first, vo
 
 /* dst[s] = src[s] for the whole samples s in sample_list (device array of `count` ints), bf16 [samples, elems_per_sample] */
 int vitk_copy_samples(const void* src, void* dst, const int* sample_list, int count, int64_t elems_per_sample, void* stream);
+/* dst (device) = pinned_src (page-locked host memory, device-accessible) as an ordinary launch on the stream: the small
+ * per-step tables of the host-side DropPath draws (models/vision_transformer.py:161,173) reach the GPU without a
+ * hipMemcpyAsync call.  bytes % 16 == 0; the host buffer must stay untouched until the launch has run. */
+int vitk_copy_from_host(const void* pinned_src, void* dst, int64_t bytes, void* stream);
 
 /* ---- elementwise helpers */
 int vitk_rowscale(const void* x, const float* rowscale, int rows_per_group, void* y, int M, int D, void* stream);

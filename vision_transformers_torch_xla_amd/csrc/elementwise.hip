@@ -320,6 +320,14 @@ __global__ void copy_samples_kernel(const uint4* __restrict__ src, uint4* __rest
     }
 }
 
+// Plain 16-byte copy.  The source may be pinned host memory (mapped into the device's address space): the per-step index tables
+// of stochastic depth are fetched this way, as an ordinary launch on the compute stream, instead of through hipMemcpyAsync -
+// whose host call was seen to block for 5-8 ms every few steps once the host runs several steps ahead, with the launch in
+// flight at that moment stretched by the same amount.
+__global__ void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // y[c * rpg + t][:] = rowscale[smap[c]] * x[smap[c] * rpg + t][:] for the nk samples of smap: the scaled gradient that enters a
 // residual branch, compact over the samples that took the branch
 __global__ void rowscale_gather_kernel(const bf16_t* __restrict__ x, const float* __restrict__ rowscale, int rows_per_group,
@@ -491,6 +499,14 @@ int vitk_copy_samples(const void* src, void* dst, const int* sample_list, int co
     const size_t per8 = (size_t)elems_per_sample / 8;
     copy_samples_kernel<<<ew_grid((size_t)count * per8), EW_BLOCK, 0, (hipStream_t)stream>>>((const uint4*)src, (uint4*)dst, sample_list, count, per8);
     return vitk_check_launch("copy_samples");
+}
+
+int vitk_copy_from_host(const void* pinned_src, void* dst, int64_t bytes, void* stream) {
+    VITK_REQUIRE(pinned_src && dst && bytes > 0, "copy_from_host: bad arguments");
+    VITK_REQUIRE(bytes % 16 == 0 && vitk_aligned(pinned_src, 16) && vitk_aligned(dst, 16), "copy_from_host: 16-byte multiples and alignment");
+    const size_t n16 = (size_t)bytes / 16;
+    copy16_kernel<<<ew_grid(n16), EW_BLOCK, 0, (hipStream_t)stream>>>((const uint4*)pinned_src, (uint4*)dst, n16);
+    return vitk_check_launch("copy_from_host");
 }
 
 int vitk_rowscale_gather(const void* x, const float* rowscale, int rows_per_group, const int* sample_map, int nk, void* y, int D,

@@ -265,6 +265,15 @@ def copy_samples(src, dst, sample_list, elems_per_sample):
     return dst
 
 
+def copy_from_pinned(src, device):
+    """device copy of a pinned host tensor, made by a kernel that reads the host memory (no hipMemcpyAsync call)"""
+    if src.is_cuda or not src.is_pinned() or not src.is_contiguous():
+        raise _lib.VitkError("copy_from_pinned: expected a contiguous pinned host tensor")
+    dst = torch.empty(src.shape, dtype=src.dtype, device=device)
+    check(_lib.load().vitk_copy_from_host(src.data_ptr(), _ptr(dst), src.numel() * src.element_size(), _stream()), "copy_from_host")
+    return dst
+
+
 def cast_f32_to_bf16(src, dst=None):
     _chk(src, f32, "src")
     if dst is None:

@@ -115,8 +115,12 @@ class _Branch:
         ints, flts = ring.next(2 * R * B)
         ints[:R * B].view(R, B).copy_(order); ints[R * B:].view(R, B).copy_(inv)
         flts[:R * B].view(R, B).copy_(scale); flts[R * B:].view(R, B).copy_((1.0 / keep)[:, None].expand(R, B))
-        gi = ints.to(device, non_blocking=True)
-        gf = flts.to(device, non_blocking=True)
+        if torch.device(device).type == "cuda" and (2 * R * B) % 4 == 0:
+            gi = ops.copy_from_pinned(ints, device)
+            gf = ops.copy_from_pinned(flts, device)
+        else:
+            gi = ints.to(device, non_blocking=True)
+            gf = flts.to(device, non_blocking=True)
         ring.copied()
         out = []
         for r in range(R):
@@ -525,13 +529,17 @@ class VisionTransformer(nn.Module):
 
     # --------------------------------------------------------------------------------------------- backward
     def _wgrad_stream(self):
-        """side stream of the weight-gradient GEMMs (VITK_WGRAD_STREAM=0 turns it off), None: everything on the current stream"""
-        if os.environ.get("VITK_WGRAD_STREAM", "1") == "0":
+        """side stream of the weight-gradient GEMMs, None: everything on the current stream.  Used when one GPU trains alone
+        (VITK_WGRAD_STREAM=0 turns it off, =2 forces it on beside a gradient reducer): next to the reducer's communication
+        stream a third stream measured slower than none.  The stream has the default priority - a high-priority stream that
+        waits on events of a lower-priority one can starve that one of the queue slot it needs to record them."""
+        mode = os.environ.get("VITK_WGRAD_STREAM", "1")
+        if mode == "0" or (self._grad_ready_hook is not None and mode != "2"):
             return None
         if ops.prof_enabled():       # an event-bracketed launch is timed with the chip to itself
             return None
         if getattr(self, "_wgrad_side", None) is None:
-            self._wgrad_side = torch.cuda.Stream(priority=int(os.environ.get("VITK_WGRAD_PRIO", "-1")))
+            self._wgrad_side = torch.cuda.Stream()
             self._ws_side = ops.Workspace()
         return self._wgrad_side
 
