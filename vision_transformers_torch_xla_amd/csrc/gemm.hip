@@ -895,11 +895,22 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
     }
 }
 
-// out[n*ldo + k] = (accumulate ? out : 0) + sum over the R row ranges of the tile slabs, fixed order; K % 4 == 0
+// out[n*ldo + k] = (accumulate ? out : 0) + sum over the R row ranges of the tile slabs, fixed order; K % 4 == 0.
+// The blocks past tile_blocks sum the bias-gradient partials colslab [R][N] the same way (one launch instead of two).
 __global__ void reduce_tiles_kernel(const float* __restrict__ slab, int R, int T, int tiles_k, int N, int K, float* __restrict__ out,
-                                    int ldo, int accumulate) {
+                                    int ldo, int accumulate, int tile_blocks, const float* __restrict__ colslab,
+                                    float* __restrict__ dbias) {
+    if ((int)blockIdx.x >= tile_blocks) {
+        const int i = ((int)blockIdx.x - tile_blocks) * blockDim.x + threadIdx.x;
+        if (i < N) {
+            float sum = 0.f;
+            for (int r = 0; r < R; ++r) sum += colslab[(size_t)r * N + i];
+            dbias[i] = accumulate ? dbias[i] + sum : sum;
+        }
+        return;
+    }
     const size_t total4 = (size_t)N * K / 4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)tile_blocks * blockDim.x) {
         const size_t e = i * 4;
         const int n = (int)(e / K), k = (int)(e % K);
         const int tile = (n >> 8) * tiles_k + (k >> 8);
@@ -1089,14 +1100,10 @@ int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int l
         const size_t total4 = (size_t)N * K / 4;
         int rgrid = (int)((total4 + 255) / 256);
         if (rgrid > 2048) rgrid = 2048;
-        reduce_tiles_kernel<<<rgrid, 256, 0, s>>>(b.slab, q.R, q.T, q.tiles_k, N, K, C, ldc, accumulate);
-        rc = vitk_check_launch("gemm_tn_reduce");
-        if (rc) return rc;
-        if (dbias) {
-            reduce_vec_kernel<<<(N + 255) / 256, 256, 0, s>>>(b.colslab, q.R, N, dbias, accumulate);
-            rc = vitk_check_launch("gemm_tn_reduce_bias");
-        }
-        return rc;
+        const int bias_blocks = dbias ? (N + 255) / 256 : 0;
+        reduce_tiles_kernel<<<rgrid + bias_blocks, 256, 0, s>>>(b.slab, q.R, q.T, q.tiles_k, N, K, C, ldc, accumulate, rgrid, b.colslab,
+                                                                dbias);
+        return vitk_check_launch("gemm_tn_reduce");
     }
     const int splits = tn_splits(M, N, K);
     GemmTNParams p;
