@@ -149,6 +149,9 @@ class _Branch:
         return b
 
 
+_WGRAD_SIDE = {}     # device index -> (side stream of the weight-gradient GEMMs, its workspace)
+
+
 class _PinRing:
     """A few pinned host buffers reused round-robin for the per-step index tables.  The copies that read them are asynchronous
     and the host may run steps ahead of the GPU, so a slot is reused only after the event recorded behind its copies has
@@ -538,9 +541,10 @@ class VisionTransformer(nn.Module):
             return None
         if ops.prof_enabled():       # an event-bracketed launch is timed with the chip to itself
             return None
-        if getattr(self, "_wgrad_side", None) is None:
-            self._wgrad_side = torch.cuda.Stream()
-            self._ws_side = ops.Workspace()
+        dev = torch.cuda.current_device()
+        if dev not in _WGRAD_SIDE:       # one per device and process: HIP streams beyond the few hardware queues share them
+            _WGRAD_SIDE[dev] = (torch.cuda.Stream(), ops.Workspace())
+        self._wgrad_side, self._ws_side = _WGRAD_SIDE[dev]
         return self._wgrad_side
 
     def _backward_impl(self, saved, douts):
@@ -625,8 +629,12 @@ class VisionTransformer(nn.Module):
             return ops.rowscale(dx_full, br.scale, N)
 
         # Weight-gradient GEMMs have no consumer inside backward: on a side stream they fill the compute units that the tile
-        # rounds of the data-gradient GEMMs leave idle.  Their operands are kept from the allocator until the side stream is done.
+        # rounds of the data-gradient GEMMs leave idle.  Their operands stay referenced until this stream has waited for the
+        # side stream's event of the block they belong to (one block later), so the allocator hands their memory on in stream
+        # order.  (Tensor.record_stream instead would release a block only once the host SEES the side event complete: with the
+        # host a step or more ahead of the GPU every step then allocates fresh memory.)
         side = self._wgrad_stream()
+        held, lagging = [], None        # operands of the current block; (event, operands) of the block before
 
         def wgrad(dy, xin, wname, bname):
             if side is None:
@@ -637,8 +645,7 @@ class VisionTransformer(nn.Module):
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 ops.gemm_tn(dy, xin, g[wname], dbias=g[bname], accumulate=acc, ws=self._ws_side)
-            dy.record_stream(side)
-            xin.record_stream(side)
+            held.append((dy, xin))
 
         def side_event():
             if side is None:
@@ -695,6 +702,11 @@ class VisionTransformer(nn.Module):
             if self._bwd_taps is not None:       # tests: the gradients entering / between / leaving the two half-blocks
                 self._bwd_taps[i] = dict(dx_in=dx_in, dx2=dx2, dx=dx, x=x, x2=x2)
             report(self._layer_end[i], False)
+            if side is not None:
+                if lagging is not None:
+                    torch.cuda.current_stream().wait_event(lagging[0])
+                    lagging[1].clear()
+                lagging, held = (side_event(), held), []
 
         # ---- embedding: x0[b, t] = (t < prefix ? token_t : patches @ Wp^T + bp) + pos[t]
         ops.pos_tokens_bwd(dx, self._gpos2d, self._gtokens, B, N, D, npre, accumulate=acc)
