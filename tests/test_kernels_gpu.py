@@ -417,3 +417,17 @@ def test_sumsq(device):
     out = torch.zeros(1, device=device)
     ops.sumsq(x.to(device), out)
     assert abs(out.item() - x.double().pow(2).sum().item()) <= 1e-5 * x.double().pow(2).sum().item()
+
+
+def test_copy_from_pinned_host_buffer(device):
+    """the copy kernel reads page-locked host memory directly (the per-step stochastic-depth tables travel this way)"""
+    ops = _ops()
+    for n, dt in ((4, torch.int32), (2 * 24 * 512, torch.int32), (2 * 24 * 512, torch.float32), (1 << 20, torch.float32)):
+        src = torch.empty(n, dtype=dt, pin_memory=True)
+        src.copy_(torch.arange(n).to(dt))
+        got = ops.copy_from_pinned(src, device)
+        assert got.dtype == dt and torch.equal(got.cpu(), src)
+    with pytest.raises(Exception):
+        ops.copy_from_pinned(torch.zeros(8, dtype=torch.int32), device)          # pageable memory is refused
+    with pytest.raises(Exception):
+        ops.copy_from_pinned(torch.zeros(3, dtype=torch.int32).pin_memory(), device)   # not a multiple of 16 bytes

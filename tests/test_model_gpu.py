@@ -415,3 +415,27 @@ def test_random_droppath_plans(device):
     assert seen_drop
     m.eval()
     assert all(p == (None, None) for p in m._draw_drop_scales(B, device))
+
+
+def test_side_stream_weight_gradients_are_bit_identical(device, monkeypatch):
+    """Weight-gradient GEMMs on the side stream (the default on one GPU) write the gradient buffer the launch stream would
+    write: same kernels, same summation order, so the whole flat gradient is bit-identical, with random stochastic-depth
+    draws (compact branches) and over two accumulated micro-steps."""
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+    B = 8
+    x, y = _batch(B, 224, 40, 21)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VITK_WGRAD_STREAM", mode)
+        torch.manual_seed(5)
+        m = create_model("vit_small_patch16_224", num_classes=40, global_pool="avg", depth=4, drop_path_rate=0.3).to(device)
+        m.train()
+        assert (m._wgrad_stream() is not None) == (mode == "1")
+        torch.manual_seed(17)                                  # the host-side DropPath draws
+        for _ in range(2):                                     # the second backward accumulates into the first
+            LabelSmoothingCrossEntropy(0.1)(m(x.to(device)), y.to(device)).backward()
+        torch.cuda.synchronize()
+        res[mode] = m._flat["g"].clone()
+    assert torch.count_nonzero(res["1"]) > 0.9 * res["1"].numel()
+    assert torch.equal(res["0"], res["1"])
