@@ -720,7 +720,8 @@ static int tn_splits(int M, int N, int K) {
 //  * 8 waves (2 x 4), each 128 (n) x 64 (k) = 8 x 4 MFMA tiles; operands global -> LDS by DMA into a double-buffered
 //    128 KB image [m][256 columns]; fragments come from the transposing read (ds_read_b64_tr_b16), one phase ahead.
 //  * rows past M (last step of the last range) are fetched from a zero row, so they add nothing.
-//  * the bias gradient (column sums of A) rides along as MFMAs against an all-ones fragment in the k-tile-0 tasks.
+//  * the bias gradient (column sums of A) rides along as MFMAs against an all-ones fragment, shared out over the waves of the
+//    tasks that read the same A columns.
 struct GemmTNBigParams {
     const bf16_t* A; int lda;
     const bf16_t* B; int ldb;
@@ -734,6 +735,7 @@ __device__ __attribute__((aligned(512))) unsigned vitk_zero_row[128];     // 512
 
 
 #define TNB_TILE (64 * 256)      // elements per operand tile: 64 rows x 256 columns
+template <int V> struct itag { static constexpr int value = V; };
 
 template <bool COLSUM>
 __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) {
@@ -752,7 +754,15 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
     const int n0 = tn_ * 256, k0 = (tile - tn_ * p.tiles_k) * 256;
     const int step0 = (int)(((long long)range * p.steps_total) / p.R);
     const int nsteps = (int)(((long long)(range + 1) * p.steps_total) / p.R) - step0;      // >= 2 (host)
-    const bool do_colsum = COLSUM && k0 == 0;
+    // Bias gradient = column sums of A over this range's rows, as MFMAs against an all-ones fragment.  The 8 row tiles (16
+    // columns of A each) of a wave row wm are shared out over the 8 waves of the first TWO k-tile tasks of an n tile (tiles_k >= 2,
+    // host): wave wn of task k-tile j sums row tile 4j + wn.  A wave walks its row tiles in a permuted order - tile index XOR
+    // (4j + wn), folded into the fragment address - so the tile it sums is always fragment 0 of the first half: one copy of
+    // the loop with two extra MFMAs per step, one without.  (All of it in the k-tile-0 tasks - four extra MFMAs per step -
+    // made those the stragglers of every launch: +6 %.)
+    const int ktile = tile - tn_ * p.tiles_k;
+    const bool cs_role = COLSUM && ktile < 2;
+    const int tperm = COLSUM ? (((ktile & 1) << 2) | wn) : 0;       // accumulator tile tm holds row tile tm ^ tperm
 
     // staging: a piece (one wave-instruction, 1 KB) is 2 rows x 512 B; wave w, piece j -> local rows (4w+j)*2 + lane/32;
     // LDS position lane%32 of row m receives source chunk (lane%32) ^ tn_swz(m)
@@ -790,14 +800,14 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
     // fragment addresses: rows r0 = ks*32 + 8*lg + lq (and +4), tn_swz(r0) is the same for both ks; the lane's 4 columns of
     // MFMA tile t are half (lp&1) of chunk (tile base chunk | lp>>1), XOR-swizzled
     const int sw = tn_swz(8 * lg + lq);
-    const int preA = ((wm * 16) | (lp >> 1)) ^ sw, preB = ((wn * 8) | (lp >> 1)) ^ sw;
+    const int preA = ((wm * 16) | (lp >> 1)) ^ sw ^ (tperm << 1), preB = ((wn * 8) | (lp >> 1)) ^ sw;
     const int rbase = (8 * lg + lq) * 256 + (lp & 1) * 4;
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 cs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 cs = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
     bf16x8 faE[4], faO[4], fbE[4], fbO[4];
     auto ldA = [&](bf16x8 (&f)[4], const bf16_t* cA, int ks, int h) {
@@ -814,22 +824,17 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
             f[t] = tr_frag(q, q + 4 * 256);
         }
     };
-    auto mma = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4], int h) {
+    // CS = 1: this wave sums the columns of its fragment 0.  CS and h are compile-time so that the pipelined loop has no branch
+    // in it: with a run-time test around the extra MFMAs hipcc lost the interleaving of the phases.
+    auto mma = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4], auto htag, auto cstag) {
+        constexpr int h = decltype(htag)::value;
+        constexpr int CS = decltype(cstag)::value;
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
                 acc[4 * h + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[4 * h + tm][tn], 0, 0, 0);
-        // column sums of A: wave (wm, wn) owns row tiles 2*wn and 2*wn+1 of its 128 rows
-        if (do_colsum && h == (wn >> 1)) {
-            if (wn & 1) {
-                cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[2], cs[0], 0, 0, 0);
-                cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[3], cs[1], 0, 0, 0);
-            } else {
-                cs[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0], cs[0], 0, 0, 0);
-                cs[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[1], cs[1], 0, 0, 0);
-            }
-        }
+        if constexpr (CS > 0 && h == 0) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[0], cs, 0, 0, 0);
     };
 
     stage(0, 0, 0);
@@ -842,6 +847,7 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
     ldB(fbE, lsm + TNB_TILE, 0);
     ldA(faE, lsm, 0, 0);
 
+    auto run = [&](auto cstag) {
     for (int st = 0; st < nsteps; ++st) {
         const int par = st & 1;
         const bf16_t* cA = lsm + par * 2 * TNB_TILE;
@@ -851,18 +857,18 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
         // same four-phase pipeline as the persistent gemm_nt kernel: 16 MFMAs on fragments fetched a phase ago, interleaved
         // with the transposing reads for the next phase
         if (st >= 1 && st + 1 < nsteps) stage(st + 1, par ^ 1, 1);      // second half of the request made in the previous step
-        mma(faE, fbE, 0);
+        mma(faE, fbE, itag<0>{}, cstag);
         ldA(faO, cA, 0, 1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
         __builtin_amdgcn_sched_barrier(0);
-        mma(faO, fbE, 1);
+        mma(faO, fbE, itag<1>{}, cstag);
         ldB(fbO, cB, 1);
         ldA(faE, cA, 1, 0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
         __builtin_amdgcn_sched_barrier(0);
-        mma(faE, fbO, 0);
+        mma(faE, fbO, itag<0>{}, cstag);
         ldA(faO, cA, 1, 1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
@@ -871,13 +877,17 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (st + 2 < nsteps) stage(st + 2, par, 0);
-        mma(faO, fbO, 1);
+        mma(faO, fbO, itag<1>{}, cstag);
         ldB(fbE, nB, 0);
         ldA(faE, nA, 0, 0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
         __builtin_amdgcn_sched_barrier(0);
     }
+    };
+    // one copy of the loop with the column sums, one without (wave-uniform choice; both meet the same barriers)
+    if (cs_role) run(itag<1>{});
+    else run(itag<0>{});
 
     // partial tile -> slab (streaming): lane = row lr of MFMA tile tm, 4 consecutive k
     float* slab = p.slab + (size_t)task * (256 * 256);
@@ -885,13 +895,10 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
     for (int tm = 0; tm < 8; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
-            __builtin_nontemporal_store(acc[tm][tn], reinterpret_cast<f32x4*>(slab + (wm * 128 + tm * 16 + lr) * 256 + wn * 64 + tn * 16 + 4 * lg));
-    if (do_colsum && lg == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int n = n0 + wm * 128 + (2 * wn + i) * 16 + lr;
-            if (n < p.N) p.colslab[(size_t)range * p.N + n] = cs[i][0];
-        }
+            __builtin_nontemporal_store(acc[tm][tn], reinterpret_cast<f32x4*>(slab + (wm * 128 + (tm ^ tperm) * 16 + lr) * 256 + wn * 64 + tn * 16 + 4 * lg));
+    if (cs_role && lg == 0) {
+        const int n = n0 + wm * 128 + tperm * 16 + lr;
+        if (n < p.N) p.colslab[(size_t)range * p.N + n] = cs[0];
     }
 }
 
@@ -928,7 +935,7 @@ struct TnPlan { bool big; int T, tiles_k, R, steps_total; };
 static TnPlan tn_plan(int M, int N, int K) {
     TnPlan q = {false, 0, 0, 0, 0};
     static const bool force_small = getenv("VITK_GEMM_SMALL") != nullptr;
-    if (force_small || M < 8192 || N < 256 || K < 256) return q;
+    if (force_small || M < 8192 || N < 256 || K <= 256) return q;      // two k tiles at least: they share the bias gradient
     q.tiles_k = (K + 255) / 256;
     q.T = ((N + 255) / 256) * q.tiles_k;
     q.steps_total = (M + 63) / 64;
