@@ -91,6 +91,12 @@ def main():
     ap.add_argument("--prof-every", type=int, default=5, help="bracket the kernel launches of every n-th timed step with HIP events")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: everything a library prints there (RCCL writes a version banner to
+    # stdout under NCCL_DEBUG=VERSION) goes to stderr instead, at the file-descriptor level
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     if os.environ.get("VITK_BENCH_WATCHDOG"):        # debugging aid: dump every thread's stack and exit if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["VITK_BENCH_WATCHDOG"]), exit=True)
@@ -227,7 +233,8 @@ def main():
             except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
                 log(f"[bench] cpu baseline failed: {e!r}")
                 result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
