@@ -58,7 +58,7 @@ class SyntheticLoader:
             self.prof_switch(False)
 
 
-def cpu_baseline(batch=16, steps=2, threads=None):
+def cpu_baseline(batch=32, steps=3, threads=None):
     """The oracle's reference-semantics fp32 train step (engine.py:257-274 restated) on this box's host cores."""
     from oracle import ref_engine, ref_ops
     from oracle.ref_vit import create_ref_model
