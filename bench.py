@@ -20,6 +20,13 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# Eight hardware queues per process (HIP reads this when it starts; its default is 4): the launch stream, the weight-gradient side
+# stream, the gradient reducer's stream and RCCL's own stream then each have a queue of their own.
+try:
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+except ValueError:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 import torch
 import torch.distributed as dist

@@ -532,13 +532,23 @@ class VisionTransformer(nn.Module):
 
     # --------------------------------------------------------------------------------------------- backward
     def _wgrad_stream(self):
-        """side stream of the weight-gradient GEMMs, None: everything on the current stream.  Used when one GPU trains alone
-        (VITK_WGRAD_STREAM=0 turns it off, =2 forces it on beside a gradient reducer): next to the reducer's communication
-        stream a third stream measured slower than none.  The stream has the default priority - a high-priority stream that
-        waits on events of a lower-priority one can starve that one of the queue slot it needs to record them."""
+        """side stream of the weight-gradient GEMMs, None: everything on the current stream (VITK_WGRAD_STREAM=0 turns it off,
+        =2 forces it on).  Beside a gradient reducer it is used only when the process has at least 8 hardware queues
+        (GPU_MAX_HW_QUEUES, read by HIP when it starts): with HIP's default of 4 the launch stream, this stream, the reducer's
+        stream and RCCL's own share queues, and a stream that shares the launch stream's queue serialises against it (measured
+        with RCCL collectives in flight: 4 queues -0.7 %, 8 queues +1.2 % against no side stream).  The stream has the default
+        priority - a high-priority stream that waits on events of a lower-priority one can starve that one of the queue slot
+        it needs to record them."""
         mode = os.environ.get("VITK_WGRAD_STREAM", "1")
-        if mode == "0" or (self._grad_ready_hook is not None and mode != "2"):
+        if mode == "0":
             return None
+        if self._grad_ready_hook is not None and mode != "2":
+            try:
+                queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+            except ValueError:
+                queues = 4
+            if queues < 8:
+                return None
         if ops.prof_enabled():       # an event-bracketed launch is timed with the chip to itself
             return None
         dev = torch.cuda.current_device()
