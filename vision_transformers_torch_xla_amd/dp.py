@@ -58,7 +58,10 @@ class GradReducer:
             return
         if after is not None:
             self._after = after
-        if final or upto - self._done >= self.bucket_elems:
+        # a bucket's worth is ready - or less than a bucket is left after this point: then what is ready goes now, so that the
+        # last collective of the step, the only one nothing overlaps, is as small as it can be
+        remaining = self._get().numel() - upto
+        if final or upto - self._done >= self.bucket_elems or (upto > self._done and remaining < self.bucket_elems):
             self._launch(self._done, upto)
             self._done = upto
         if final:
