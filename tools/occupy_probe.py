@@ -60,5 +60,5 @@ def run(label, hook):
 
 run("no hook (side stream on)", None)
 run("hook, no occupier (one stream)", make_hook(0, 0, 1))
-for wgs, us in ((16, 300), (32, 300), (64, 300), (32, 1000)):
-    run(f"occupier {wgs} workgroups x {us} us, 13 per step", make_hook(wgs, us, 1))
+for wgs, us, every in ((16, 300, 1), (32, 300, 1), (32, 1000, 1), (8, 300, 1), (8, 600, 2), (16, 600, 2)):
+    run(f"occupier {wgs} workgroups x {us} us, {13 // every + (every > 1)} per step", make_hook(wgs, us, every))
