@@ -474,15 +474,11 @@ int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int
     const int maxt = 2 * ((N + 31) / 32);
     const size_t smem = (size_t)2 * maxt * 16 * HD * sizeof(bf16_t);
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_done[40] = {false};
+    static VitkLdsOnce attr_done[40] = {};
     const bool pr = vitk_prof_begin(stream, 8.0 * (double)B * (double)N * (double)H * HD, VITK_PROF_ATTN_FWD);
 #define VITK_FWD_CASE(T, W, E)                                                                                              \
     case T: {                                                                                                               \
-        if (!attr_done[T]) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, W, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-            if (e != hipSuccess) { vitk_set_error("attention_fwd: cannot set LDS size %zu: %s", smem, hipGetErrorString(e)); return VITK_ELAUNCH; } \
-            attr_done[T] = true;                                                                                            \
-        }                                                                                                                   \
+        if (int rc_ = vitk_lds_once(attr_done[T], (const void*)attn_fwd_kernel<T, W, E>, smem, "attention_fwd")) return rc_;          \
         attn_fwd_kernel<T, W, E><<<B * H, W * 64, smem, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);          \
     } break;
     switch (maxt) {
@@ -512,15 +508,11 @@ int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const
     const int maxt = 2 * ((N + 31) / 32);
     const size_t smem = (size_t)2 * maxt * 16 * HD * sizeof(bf16_t) + (size_t)2 * maxt * 16 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_done[40] = {false};
+    static VitkLdsOnce attr_done[40] = {};
     const bool pr = vitk_prof_begin(stream, 16.0 * (double)B * (double)N * (double)H * HD, VITK_PROF_ATTN_BWD);
 #define VITK_BWD_CASE(T, W, E)                                                                                                 \
     case T: {                                                                                                               \
-        if (!attr_done[T]) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_res_kernel<T, W, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-            if (e != hipSuccess) { vitk_set_error("attention_bwd: cannot set LDS size %zu: %s", smem, hipGetErrorString(e)); return VITK_ELAUNCH; } \
-            attr_done[T] = true;                                                                                            \
-        }                                                                                                                   \
+        if (int rc_ = vitk_lds_once(attr_done[T], (const void*)attn_bwd_res_kernel<T, W, E>, smem, "attention_bwd")) return rc_;          \
         attn_bwd_res_kernel<T, W, E><<<B * H, W * 64, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, \
                                                               (bf16_t*)dqkv, N, H, scale);                                  \
     } break;

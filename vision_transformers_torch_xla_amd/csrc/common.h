@@ -143,3 +143,22 @@ int vitk_check_launch(const char* what);
     } while (0)
 
 static inline bool vitk_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Kernels that declare more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per kernel
+// AND per device (a process that drives several GPUs sets it on each).  Returns 0 or VITK_ELAUNCH with the error text set.
+struct VitkLdsOnce { bool done[64]; };
+static inline int vitk_lds_once(VitkLdsOnce& st, const void* fn, size_t bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        vitk_set_error("%s: cannot query the current device", what);
+        return VITK_ELAUNCH;
+    }
+    if (st.done[dev]) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        vitk_set_error("%s: cannot set LDS size %zu: %s", what, bytes, hipGetErrorString(e));
+        return VITK_ELAUNCH;
+    }
+    st.done[dev] = true;
+    return 0;
+}

@@ -1009,12 +1009,8 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
         const int grid = p.num_tiles < cus ? p.num_tiles : cus;      // one persistent workgroup per CU
 #define VITK_LAUNCH_BIG(E)                                                                                              \
     case E: {                                                                                                           \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-            if (e != hipSuccess) { vitk_set_error("gemm_nt: cannot set LDS size: %s", hipGetErrorString(e)); return VITK_ELAUNCH; }    \
-            attr_set = true;                                                                                            \
-        }                                                                                                               \
+        static VitkLdsOnce once = {};                                                                                   \
+        if (int rc_ = vitk_lds_once(once, (const void*)gemm_ntp_kernel<E>, smem, "gemm_nt")) return rc_;                \
         gemm_ntp_kernel<E><<<grid, 512, smem, s>>>(p);                                                         \
     } break;
         switch (epilogue) {
@@ -1091,13 +1087,9 @@ int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int l
         b.M = M; b.N = N; b.K = K; b.T = q.T; b.tiles_k = q.tiles_k; b.R = q.R; b.steps_total = q.steps_total;
         b.ntasks = q.R * q.T;
         const size_t smem = (size_t)4 * TNB_TILE * sizeof(bf16_t);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_tnb_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tnb_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) { vitk_set_error("gemm_tn: cannot set LDS size: %s", hipGetErrorString(e)); return VITK_ELAUNCH; }
-            attr_set = true;
-        }
+        static VitkLdsOnce once_t = {}, once_f = {};
+        if (int rc_ = vitk_lds_once(once_t, (const void*)gemm_tnb_kernel<true>, smem, "gemm_tn")) return rc_;
+        if (int rc_ = vitk_lds_once(once_f, (const void*)gemm_tnb_kernel<false>, smem, "gemm_tn")) return rc_;
         const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_TN);
         if (dbias) gemm_tnb_kernel<true><<<b.ntasks, 512, smem, s>>>(b);
         else gemm_tnb_kernel<false><<<b.ntasks, 512, smem, s>>>(b);
