@@ -78,6 +78,16 @@ size_t vitk_layernorm_bwd_workspace(int M, int D);
 int vitk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                        const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate,
                        int M, int D, void* workspace, size_t workspace_bytes, void* stream);
+/* vitk_layernorm_bwd without a workspace argument and without any allocation.  No counterpart in the reference: it is for
+ * callers that cannot allocate device memory around the call - code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  The partial sums of dgamma / dbeta go to a scratch array inside the library (8 MB per GPU, held
+ * until the process ends), sized for the largest accepted shape: any M, D <= 1024; anything else is rejected before a launch.
+ * Results are bit-identical to vitk_layernorm_bwd.  All calls on one GPU share that GPU's scratch: calls that overlap on one
+ * GPU (different streams, or different threads) race; calls on one stream are ordered and safe.  The first call on a device
+ * looks the scratch address up (hipGetSymbolAddress): make it before stream capture begins. */
+int vitk_layernorm_bwd_noalloc(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                               const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate, int M, int D,
+                               void* stream);
 /* The same, and also dx_scaled_bf16[row] = rowscale[row / rows_per_group] * dx_bf16[row]: the gradient entering the next
  * residual branch under stochastic depth (timm DropPath in Block.forward, models/vision_transformer.py:164-171), written
  * in the same pass instead of by vitk_rowscale. */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "vitk_layernorm_bwd_gather": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vitk_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "vitk_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "vitk_layernorm_bwd_noalloc": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vitk_layernorm_bwd_scaled": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vitk_gemm_nt": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p]),
     "vitk_gemm_nt_res_scatter": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p]),

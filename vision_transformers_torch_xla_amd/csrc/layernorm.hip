@@ -2,6 +2,7 @@
 // HBM-bound: forward moves 4 B/element (read x, write y), backward 6 B/element (read dy, x; write dx)
 // plus 2 B/element when the residual gradient is fused in.
 #include "common.h"
+#include <mutex>
 
 bool vitk_prof_begin(void* stream, double flop, int kind);
 void vitk_prof_end(void* stream);
@@ -288,6 +289,36 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
     }
 }
 
+// Scratch of vitk_layernorm_bwd_noalloc: the dgamma / dbeta partial rows [blocks <= 1024][2][D <= 1024] that the other
+// backward entry points take from the caller's workspace.  One copy per GPU the library runs on (8 MB each, held until the
+// process ends).  In host code the array's NAME is only a stand-in: its device address comes from hipGetSymbolAddress, once
+// per device, and that pointer is what kernels receive.
+#define LN_SCRATCH_FLOATS (1024 * 2 * 1024)
+static __device__ __align__(256) float ln_scratch[LN_SCRATCH_FLOATS];
+
+static std::mutex g_ln_scratch_mu;
+static float* g_ln_scratch_ptr[64] = {nullptr};
+
+// device address of ln_scratch on the current device (looked up on the first call per device); null + error text on failure
+static float* ln_scratch_ptr() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        vitk_set_error("layernorm_bwd_noalloc: cannot query the current device");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_ln_scratch_mu);
+    if (g_ln_scratch_ptr[dev] == nullptr) {
+        float* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(ln_scratch));
+        if (e != hipSuccess || ptr == nullptr) {
+            vitk_set_error("layernorm_bwd_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return nullptr;
+        }
+        g_ln_scratch_ptr[dev] = ptr;
+    }
+    return g_ln_scratch_ptr[dev];
+}
+
 static int ln_grid(int M) {
     int g = (M + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
     return g < LN_MAX_BLOCKS ? g : LN_MAX_BLOCKS;
@@ -380,6 +411,24 @@ int vitk_layernorm_bwd(const void* dy, const void* x, const float* mean, const f
                        void* workspace, size_t workspace_bytes, void* stream) {
     return ln_bwd_impl(dy, x, mean, rstd, gamma, dres, dx, nullptr, 0, nullptr, dgamma, dbeta, accumulate, M, D, workspace,
                        workspace_bytes, stream);
+}
+
+int vitk_layernorm_bwd_noalloc(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                               const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate, int M, int D,
+                               void* stream) {
+    // sizes first: nothing is looked up or launched for a shape the scratch array cannot hold
+    VITK_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 1024,
+                 "layernorm_bwd_noalloc: need M>0, D%%8==0 and D <= 1024, the row width the library's own scratch is sized for (M=%d D=%d)", M, D);
+    const size_t need = vitk_layernorm_bwd_workspace(M, D);
+    if (need > sizeof(float) * (size_t)LN_SCRATCH_FLOATS) {
+        vitk_set_error("layernorm_bwd_noalloc: %zu bytes of partial sums exceed the %zu-byte scratch", need, sizeof(float) * (size_t)LN_SCRATCH_FLOATS);
+        return VITK_ENOSPC;
+    }
+    float* scratch = ln_scratch_ptr();
+    if (scratch == nullptr) return VITK_ELAUNCH;
+    // every partial row the reduction reads is written by the first kernel of this call: nothing has to start at zero
+    return ln_bwd_impl(dy, x, mean, rstd, gamma, dres, dx, nullptr, 0, nullptr, dgamma, dbeta, accumulate, M, D, scratch,
+                       sizeof(float) * (size_t)LN_SCRATCH_FLOATS, stream);
 }
 
 int vitk_layernorm_bwd_scaled(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
