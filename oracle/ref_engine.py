@@ -18,10 +18,63 @@ def make_optimizer(model, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8):
     return torch.optim.AdamW(groups, lr=lr, weight_decay=0.0, betas=betas, eps=eps)
 
 
+class RefStudentWithDistillation(torch.nn.Module):
+    """main.py:836-851 (duplicated at test_kd.py:43-58): in train mode (student(x), teacher(x) under no_grad), in eval mode
+    student(x).  forward_kwargs reach both models (the oracle's emulate= switch)."""
+
+    def __init__(self, student_model, teacher_model):
+        super().__init__()
+        self.student = student_model
+        self.teacher = teacher_model
+
+    def forward(self, x, **kw):
+        student_logits = self.student(x, **kw)
+        if self.training and self.teacher is not None:
+            with torch.no_grad():
+                teacher_logits = self.teacher(x, **kw)
+            return student_logits, teacher_logits
+        return student_logits
+
+
+class RefDistillationLoss(torch.nn.Module):
+    """main.py:939-970: (1 - alpha) * base(student, y) + alpha * T^2 * KLDiv_batchmean(log_softmax(s/T), softmax(t/T)) for a
+    (student, teacher) tuple, base(outputs, y) for a plain tensor."""
+
+    def __init__(self, base_criterion, alpha=0.7, temperature=4.0):
+        super().__init__()
+        self.base_criterion, self.alpha, self.temperature = base_criterion, alpha, temperature
+
+    def forward(self, outputs, targets):
+        if isinstance(outputs, tuple):
+            return R.distillation_loss(outputs[0], outputs[1], targets, self.base_criterion, self.alpha, self.temperature)
+        return self.base_criterion(outputs, targets)
+
+
+class RefModelEma:
+    """timm.utils.ModelEma as engine.py:198-202,273-274 uses it: a deep copy in eval mode whose every state-dict entry
+    becomes decay * ema + (1 - decay) * model after each optimizer step."""
+
+    def __init__(self, model, decay=0.9999):
+        import copy
+        self.ema = copy.deepcopy(model)
+        self.ema.eval()
+        self.decay = decay
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+
+    @torch.no_grad()
+    def update(self, model):
+        msd = model.state_dict()
+        for k, ema_v in self.ema.state_dict().items():
+            ema_v.copy_(ema_v * self.decay + (1.0 - self.decay) * msd[k].detach())
+
+
 def ref_train_one_epoch(model, criterion, data_loader, optimizer, start_steps=0, lr_schedule_values=None,
                         wd_schedule_values=None, num_training_steps_per_epoch=None, update_freq=1, forward_kwargs=None,
-                        record=None):
-    """Returns {'loss', 'lr', 'class_acc'} global averages, like engine.py:333 with mixup off and log_freq=1."""
+                        record=None, max_norm=0, model_ema=None):
+    """Returns {'loss', 'lr', 'class_acc'} global averages, like engine.py:333 with mixup off and log_freq=1.
+    max_norm > 0 clips the total gradient norm before the optimizer step (engine.py:175-177); model_ema.update(model)
+    follows every optimizer step (engine.py:198-202, 273-274)."""
     model.train(True)
     optimizer.zero_grad()
     tot = {"loss": 0.0, "lr": 0.0, "class_acc": 0.0}
@@ -46,8 +99,12 @@ def ref_train_one_epoch(model, criterion, data_loader, optimizer, start_steps=0,
         if record is not None:
             record(data_iter_step, output, loss_value, model)
         if (data_iter_step + 1) % update_freq == 0:
+            if max_norm is not None and max_norm > 0:                              # engine.py:175-177
+                torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], max_norm)
             optimizer.step()
             optimizer.zero_grad()
+            if model_ema is not None:                                              # engine.py:198-202, 273-274
+                model_ema.update(model)
         out0 = output[0] if isinstance(output, tuple) else output
         class_acc = (out0.max(-1)[-1] == targets).float().mean().item()          # engine.py:283
         tot["loss"] += loss.item(); cnt["loss"] += 1                               # engine.py:294 logs loss/update_freq

@@ -126,10 +126,22 @@ def test_flat_layout_invariants():
     assert ends == sorted(ends) and ends[-1] <= m._decay_end
     # deepcopy / zero_grad
     import copy
+    m.blocks[0].norm1.weight.requires_grad_(False)
+    m._grad_ready_hook = lambda *a, **k: None
     c = copy.deepcopy(m)
-    assert not c._views_ok()
-    c._flatten()
-    assert c._views_ok() and torch.equal(c.head.weight, m.head.weight)
+    assert c._views_ok() and torch.equal(c._flat["p"], m._flat["p"]) and c._flat["p"].data_ptr() != m._flat["p"].data_ptr()
+    assert [n for n, _ in c.named_parameters()] == [n for n, _ in m.named_parameters()]
+    assert [p.requires_grad for p in c.parameters()] == [p.requires_grad for p in m.parameters()]
+    # runtime objects are rebuilt, not shared or copied; an evaluation copy holds no gradient buffer
+    assert c._pin_ring is not m._pin_ring and c._ws is not m._ws and c._grad_ready_hook is None
+    assert c._flat["g"] is None and m._flat["g"] is not None
+    assert c._ensure_grad_buffer().shape == m._flat["g"].shape and c._gview["head.weight"].shape == m.head.weight.shape
+    # timm's parameter order for the distilled model (optimizer state dicts are matched by index)
+    assert [n for n, _ in m.named_parameters()][:3] == ["cls_token", "pos_embed", "dist_token"]
+    # a re-flatten drops the transposed-weight table together with the buffers it describes
+    m._wt_plan, m._wt_plan_key = "stale", ("stale",)
+    m._flatten()
+    assert m._wt_plan is None and m._wt_plan_key is None and m._wt == {}
 
 
 def test_parameter_groups_and_optimizer_plan():

@@ -68,9 +68,10 @@ def _worker(rank, world, port, tmp):
         model.zero_grad()
         crit(ddp(X[4 * rank:4 * rank + 4]), Y[4 * rank:4 * rank + 4]).backward()
         launched = list(ddp.reducer.launched)
-        ddp.reducer.wait()
-        torch.cuda.synchronize()
+        # no reducer.wait(): backward itself orders this stream after every bucket, so a plain reader of the gradients
+        # (this clone, enqueued on the launch stream before any host synchronisation) sees the averaged values
         got = model._flat["g"].clone()
+        torch.cuda.synchronize()
         assert launched[0][0] == 0 and launched[-1][1] == model._total and len(launched) >= 3, launched
         assert all(a[1] == b[0] for a, b in zip(launched, launched[1:]))
         assert torch.equal(got, want), float((got - want).abs().max())

@@ -33,11 +33,15 @@ __global__ __launch_bounds__(256) void xent_label_kernel(const float* __restrict
     for (int c = threadIdx.x; c < C; c += 256) se += __expf(x[c] - mx);
     se = block_sum(se, sh);
     const float lse = mx + __logf(se);
-    const int t = (int)target[row];
+    // A label outside [0, C) (a foreign ignore_index, a class count that does not match the head) must never become an
+    // address: the row's loss and gradient are NaN, so the step fails loudly where torch would raise.
+    const int64_t t64 = target[row];
+    const bool valid = t64 >= 0 && t64 < (int64_t)C;
+    const int t = valid ? (int)t64 : 0;
     if (threadIdx.x == 0) {
         const float nll = lse - x[t];
         const float smooth = lse - sx / (float)C;
-        loss_rows[row] = (1.0f - smoothing) * nll + smoothing * smooth;
+        loss_rows[row] = valid ? (1.0f - smoothing) * nll + smoothing * smooth : __builtin_nanf("");
     }
     if (dlogits != nullptr) {
         float* d = dlogits + (size_t)row * lddl;
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void xent_label_kernel(const float* __restrict
         for (int c = threadIdx.x; c < C; c += 256) {
             float g = __expf(x[c] - mx) * inv - u;
             if (c == t) g -= (1.0f - smoothing);
-            d[c] = g * grad_scale;
+            d[c] = valid ? g * grad_scale : __builtin_nanf("");
         }
     }
 }

@@ -40,7 +40,8 @@ class GradReducer:
         self._stream = None
         self._events = []
         self._after = None        # latest event of a stream other than the current one that also writes gradients
-        self.launched = []        # (start, end) slices reduced in the current backward, for tests / introspection
+        self.launched = []        # (start, end) slices reduced in the last backward, for tests / introspection
+        self._new_pass = True     # the next report starts a new backward pass
 
     def _side_stream(self, device):
         if self._stream is None or self._stream.device != device:
@@ -52,10 +53,14 @@ class GradReducer:
         when backward writes some gradients on another stream, once `after` (an event recorded on that stream; later events
         supersede earlier ones) has completed.  Reduce [done, upto) once it is a bucket's worth (or at the end)."""
         if not self.enabled or self._skip:
+            self.launched = []
             if final:
                 self._done = 0
                 self._after = None
             return
+        if self._new_pass:
+            self.launched = []
+            self._new_pass = False
         if after is not None:
             self._after = after
         # a bucket's worth is ready - or less than a bucket is left after this point: then what is ready goes now, so that the
@@ -67,6 +72,11 @@ class GradReducer:
         if final:
             self._done = 0
             self._after = None
+            self._new_pass = True
+            # Whatever follows backward on this stream (clipping, the optimizer step, a reader of .grad) reads the AVERAGED
+            # gradients: the stream waits here for every bucket, as torch DDP's backward does.  All collectives are already
+            # launched, so nothing of the overlap is lost.
+            self._join()
 
     def _launch(self, a, b):
         if b <= a:
@@ -104,8 +114,7 @@ class GradReducer:
             g.mul_(1.0 / self.world)
             self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
-    def wait(self):
-        """Make the current stream (or the host, for CPU tensors) wait for every outstanding bucket."""
+    def _join(self):
         for w in self._works:
             w.wait()
         self._works = []
@@ -114,7 +123,12 @@ class GradReducer:
             for ev in self._events:
                 cur.wait_event(ev)
             self._events = []
-        self.launched = []
+
+    def wait(self):
+        """Make the current stream (or the host, for CPU tensors) wait for every outstanding bucket.  Backward already does
+        this when it reports its last gradients, so after a complete backward this is a no-op kept for callers that reduce
+        by hand; calling it any number of times is harmless."""
+        self._join()
 
 
 class DistributedDataParallel(nn.Module):
@@ -129,7 +143,7 @@ class DistributedDataParallel(nn.Module):
         if not hasattr(core, "_flat"):
             raise RuntimeError("DistributedDataParallel: expected a vision_transformers_torch_xla_amd VisionTransformer")
         self._core = core
-        self.reducer = GradReducer(lambda: core._flat["g"], process_group, bucket_bytes, single_rank_collectives)
+        self.reducer = GradReducer(core._ensure_grad_buffer, process_group, bucket_bytes, single_rank_collectives)
         core._grad_ready_hook = self.reducer.ready
         if broadcast_parameters and dist.is_initialized() and not self.reducer._skip:
             if not core._views_ok():

@@ -34,7 +34,7 @@ def clip_grad_norm_(model, max_norm: float):
     """torch.nn.utils.clip_grad_norm_ (L2) over the flat gradient buffer: one sum-of-squares reduction and one
     scaling launch, the norm never leaves the GPU.  Returns the total norm as a 0-d GPU tensor."""
     core = _core_model(model)
-    g = core._flat["g"]
+    g = core._ensure_grad_buffer()
     if not hasattr(core, "_sumsq"):
         core._sumsq = torch.zeros(1, dtype=torch.float32, device=g.device)
     ops.sumsq(g, core._sumsq, ws=core._ws)

@@ -75,6 +75,11 @@ class FusedAdamW(torch.optim.Optimizer):
         if model is not None and hasattr(model, "_flat") and not model._views_ok():
             model._flatten()
         flat_ok = model is not None and hasattr(model, "_flat")
+        # A re-plan (the model was re-flattened by .to() / .cuda(), or its state was loaded) must not lose the moments
+        # gathered so far while the step count - and with it the bias correction - carries on: keep them and copy them
+        # into the new flat buffers below.
+        carried = {p: (st["exp_avg"].detach().clone(), st["exp_avg_sq"].detach().clone())
+                   for p, st in self.state.items() if "exp_avg" in st and "exp_avg_sq" in st}
         if flat_ok:
             flat_p = model._flat["p"]
             base = flat_p.data_ptr()
@@ -98,8 +103,14 @@ class FusedAdamW(torch.optim.Optimizer):
                     else:
                         cur = [start, nxt, i]
                         ranges.append(cur)
-                    self.state[p] = {"step": torch.tensor(0.0), "exp_avg": self._m[start:start + p.numel()].view(p.shape),
+                    self.state[p] = {"step": torch.tensor(float(self._steps)), "exp_avg": self._m[start:start + p.numel()].view(p.shape),
                                      "exp_avg_sq": self._v[start:start + p.numel()].view(p.shape)}
+                    if p in carried:
+                        for dst, src in zip((self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]), carried[p]):
+                            if tuple(src.shape) != tuple(dst.shape):
+                                raise VitkError(f"FusedAdamW: optimizer state of shape {tuple(src.shape)} does not fit parameter "
+                                                f"{name_of[id(p)]} of shape {tuple(dst.shape)}")
+                            dst.copy_(src.to(dst.device))
             else:
                 loose = list(group["params"])
             for p in loose:
@@ -134,7 +145,7 @@ class FusedAdamW(torch.optim.Optimizer):
                       grad_scale=self.grad_scale)
             for (a, b) in ranges:
                 f = model._flat
-                ops.adamw_step(f["p"][a:b], f["g"][a:b], self._m[a:b], self._v[a:b], p_bf16=f["b"][a:b], **kw)
+                ops.adamw_step(f["p"][a:b], model._ensure_grad_buffer()[a:b], self._m[a:b], self._v[a:b], p_bf16=f["b"][a:b], **kw)
             for p in loose:
                 if p.grad is None:
                     continue
@@ -174,6 +185,11 @@ class FusedAdamW(torch.optim.Optimizer):
             for p, st in self.state.items():
                 if id(p) in views and "exp_avg" in st:
                     m, v = views[id(p)]
+                    if tuple(st["exp_avg"].shape) != tuple(m.shape) or tuple(st["exp_avg_sq"].shape) != tuple(v.shape):
+                        # state dicts are matched by parameter INDEX: a checkpoint of a model with another parameter order
+                        # or size must not be broadcast into the wrong moments
+                        raise VitkError(f"FusedAdamW.load_state_dict: moment of shape {tuple(st['exp_avg'].shape)} does not fit a "
+                                        f"parameter of shape {tuple(m.shape)} (the checkpoint belongs to another model layout)")
                     m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
                     st["exp_avg"], st["exp_avg_sq"] = m, v
         if steps:

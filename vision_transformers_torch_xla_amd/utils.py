@@ -218,6 +218,7 @@ class ModelEma:
         from . import ops
         from ._lib import VitkError
         src = model.module if hasattr(model, "module") else model
+        src = src.student if hasattr(src, "student") else src        # knowledge distillation: the student is what is averaged (main.py:747-748)
         if not (hasattr(src, "_flat") and hasattr(self.ema, "_flat") and src._flat["p"].is_cuda):
             raise VitkError("ModelEma.update: expected the flat-buffer VisionTransformer on the GPU (no torch fallback)")
         if not self.ema._views_ok():

@@ -201,8 +201,13 @@ class _ViTFunction(torch.autograd.Function):
 class VisionTransformer(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, global_pool="token", embed_dim=768,
                  depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True, drop_path_rate=0.0, distilled=False,
-                 weight_init="", **kwargs):
+                 weight_init="", _lazy_grad=False, **kwargs):
         super().__init__()
+        # what rebuilds an identically shaped model (copy.deepcopy goes through the constructor, see __deepcopy__)
+        self._ctor = dict(img_size=img_size, patch_size=patch_size, in_chans=in_chans, num_classes=num_classes, global_pool=global_pool,
+                          embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                          drop_path_rate=drop_path_rate, distilled=distilled)
+        self._lazy_grad = bool(_lazy_grad)       # the flat gradient buffer is allocated by the first backward, not up front
         unsupported = {k: v for k, v in kwargs.items() if v not in (None, False, 0, 0.0, "")}
         for k in ("class_token", "final_norm", "pretrained_cfg", "pretrained_cfg_overlay", "cache_dir"):
             unsupported.pop(k, None)
@@ -236,10 +241,12 @@ class VisionTransformer(nn.Module):
         self.num_tokens = self.num_patches + self.num_prefix_tokens
         if self.num_tokens > 608:
             raise VitkError(f"{self.num_tokens} tokens exceed the fused attention kernel's limit (608)")
+        # registration order = timm's named_parameters() order (cls_token, pos_embed, dist_token: models/deit.py:41-43 adds the
+        # distillation token after the base class registered the other two), which optimizer state dicts are matched by
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_tokens, embed_dim))
         if distilled:
             self.dist_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
-        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_tokens, embed_dim))
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]  # vision_transformer.py:581
         self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, dpr[i]) for i in range(depth)])
         if use_fc_norm:
@@ -321,7 +328,7 @@ class VisionTransformer(nn.Module):
             off += pad
         total = off
         flat_p = torch.zeros(total, dtype=f32, device=device)
-        flat_g = torch.zeros(total, dtype=f32, device=device)
+        flat_g = None if self._lazy_grad else torch.zeros(total, dtype=f32, device=device)
         with torch.no_grad():
             for n, p in order:
                 flat_p[offs[n]:offs[n] + p.numel()].copy_(p.detach().reshape(-1).to(device=device, dtype=f32))
@@ -331,12 +338,15 @@ class VisionTransformer(nn.Module):
         for n, p in order:
             sl = slice(offs[n], offs[n] + p.numel())
             p.data = flat_p[sl].view(p.shape)
-            self._gview[n] = flat_g[sl].view(p.shape)
             p.grad = None
             self._plist.append(p)
         self._pnames = [n for n, _ in order]
         self._grad_valid = False
+        # transposed weight copies and their descriptor table belong to THIS bf16 buffer: a table kept across a re-flatten
+        # would name freed memory if the allocator ever handed the old address out again
         self._wt = {}
+        self._wt_plan = None
+        self._wt_plan_key = None
         self._weights_version = None
         # bucket boundaries for gradient reduction: grads below boundary k are final once stage k of backward is done
         self._layer_end = {}
@@ -387,10 +397,44 @@ class VisionTransformer(nn.Module):
         D, npre = self.embed_dim, self.num_prefix_tokens
         o = self._offs["cls_token"]
         self._tokens = self._flat["p"][o:o + npre * D].view(npre, D)
-        self._gtokens = self._flat["g"][o:o + npre * D].view(npre, D)
         o = self._offs["pos_embed"]
         self._pos2d = self._flat["p"][o:o + self.num_tokens * D].view(self.num_tokens, D)
-        self._gpos2d = self._flat["g"][o:o + self.num_tokens * D].view(self.num_tokens, D)
+        self._gview, self._gtokens, self._gpos2d = {}, None, None
+        if self._flat["g"] is not None:
+            self._build_grad_views()
+
+    def _build_grad_views(self):
+        flat_g, D, npre = self._flat["g"], self.embed_dim, self.num_prefix_tokens
+        self._gview = {n: flat_g[self._offs[n]:self._offs[n] + p.numel()].view(p.shape) for n, p in zip(self._pnames, self._plist)}
+        o = self._offs["cls_token"]
+        self._gtokens = flat_g[o:o + npre * D].view(npre, D)
+        o = self._offs["pos_embed"]
+        self._gpos2d = flat_g[o:o + self.num_tokens * D].view(self.num_tokens, D)
+
+    def _ensure_grad_buffer(self):
+        """the flat fp32 gradient buffer of a model built with a lazy one (deep copies: an EMA copy never trains)"""
+        if self._flat["g"] is None:
+            self._flat["g"] = torch.zeros(self._total, dtype=f32, device=self._flat["p"].device)
+            self._build_grad_views()
+        return self._flat["g"]
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) (timm ModelEma does it, engine.py:198-202 / main.py:744-754): a fresh model of the same
+        configuration with the same parameter VALUES, training flags and requires_grad flags.  Runtime objects are not
+        copied but rebuilt empty - pinned-table ring and its events, workspaces, the side stream, the transposed-weight
+        table, a data-parallel reducer's hook (the copy is not wrapped) - and the gradient buffer of the copy is allocated
+        only if it is ever trained."""
+        new = VisionTransformer(**self._ctor, weight_init="skip", _lazy_grad=True)
+        memo[id(self)] = new
+        new._flatten(self._flat["p"].device)
+        with torch.no_grad():
+            new._flat["p"].copy_(self._flat["p"])
+        for pn, po in zip(new._plist, self._plist):
+            pn.requires_grad_(po.requires_grad)
+        new.train(self.training)
+        new.distilled_training = self.distilled_training
+        new._compact_droppath = self._compact_droppath
+        return new
 
     def _refresh_transposes(self):
         """[in, out] bf16 copies of the linears: the data-gradient GEMM dX = dY @ W runs as gemm_nt(dY, W^T)."""
@@ -564,6 +608,8 @@ class VisionTransformer(nn.Module):
         M = B * N
         wb, wt, g, ws = self._wb, self._wt, self._gview, self._ws
         scale = 64 ** -0.5
+        self._ensure_grad_buffer()
+        g = self._gview
         # grads: overwrite unless a previous backward since the last zero_grad already wrote the buffer
         acc = self._grad_valid and all(p.grad is not None for p in self._plist)
         tail = saved["tail"]
