@@ -86,21 +86,35 @@ class _Attention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do_):
         q, k, v, o, lse = ctx.saved_tensors
-        scale, emulate, H = ctx.scale, ctx.emulate, ctx.H
-        B, _, N, d = q.shape
-        do = do_.reshape(B, N, H, d).transpose(1, 2)
-        p = torch.exp((q @ k.transpose(-1, -2)) * scale - lse)
-        delta = (do * o).sum(dim=-1, keepdim=True)
-        pb = rb(p) if emulate else p
-        dv = pb.transpose(-1, -2) @ do
-        dp = do @ v.transpose(-1, -2)
-        ds = p * (dp - delta) * scale
-        if emulate:
-            ds = rb(ds)
-        dq = ds @ k
-        dk = ds.transpose(-1, -2) @ q
-        dqkv = torch.stack([dq, dk, dv], dim=0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * H * d)
-        return dqkv, None, None, None
+        return _attention_backward(q, k, v, o, lse, do_, ctx.scale, ctx.emulate), None, None, None
+
+
+def _attention_backward(q, k, v, o, lse, do_, scale, emulate):
+    """q, k, v, o [B,H,N,d], lse [B,H,N,1], do_ [B,N,H*d] -> dqkv [B,N,3*H*d]"""
+    B, H, N, d = q.shape
+    do = do_.reshape(B, N, H, d).transpose(1, 2)
+    p = torch.exp((q @ k.transpose(-1, -2)) * scale - lse)
+    delta = (do * o).sum(dim=-1, keepdim=True)
+    pb = rb(p) if emulate else p
+    dv = pb.transpose(-1, -2) @ do
+    dp = do @ v.transpose(-1, -2)
+    ds = p * (dp - delta) * scale
+    if emulate:
+        ds = rb(ds)
+    dq = ds @ k
+    dk = ds.transpose(-1, -2) @ q
+    return torch.stack([dq, dk, dv], dim=0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * H * d)
+
+
+def attention_backward(qkv, out, lse, dout, H, scale=None, emulate=False):
+    """The backward of `attention` from GIVEN forward results: qkv [B,N,3*H*d], out [B,N,H*d] and lse [B,H,N] as a forward
+    pass produced them, dout [B,N,H*d] -> dqkv.  (Lets a test hand the oracle the very O and log-sum-exp the kernel under
+    test consumed, so that both sides start from identical inputs.)"""
+    B, N, D3 = qkv.shape
+    d = D3 // (3 * H)
+    q, k, v = qkv.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4)
+    o = out.reshape(B, N, H, d).transpose(1, 2)
+    return _attention_backward(q, k, v, o, lse.reshape(B, H, N, 1), dout, d ** -0.5 if scale is None else scale, emulate)
 
 
 def attention(qkv, H, scale=None, emulate=False):

@@ -1,0 +1,359 @@
+"""The branches of the training loop beside the plain step, on the GPU against the CPU oracle's restatement of the same
+branch: knowledge distillation as a workload (main.py:836-851, 939-970; test_kd.py:18-126), the weight EMA
+(engine.py:198-202, 273-274), gradient clipping (engine.py:175-177), gradient accumulation (engine.py:84-88, 268-274),
+the reference's CPU-runnable configuration at full depth (ViT-Tiny, 64 images, 12 blocks), and checkpoint resume /
+fine-tune loading followed by real steps (utils/__init__.py:686-770, main.py:653-674).
+
+Tolerances: two bf16 pipelines decorrelate at the bf16 quantisation floor after a few layers (see test_model_gpu.py), so
+results that went through the whole network are held to E2E_TOL (loss) and WEIGHT_TOL (weights after AdamW steps, which
+normalise every gradient to about lr); anything that is the same arithmetic on the same inputs is held to 1e-6 or to
+bit equality."""
+import argparse
+import copy
+
+import pytest
+import torch
+
+from tests.test_model_gpu import E2E_TOL, _batch, _pair
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+WEIGHT_TOL = 2e-3
+
+
+class _Args:
+    opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 1e-3, 0.05, 1e-8, None
+
+
+def _weights(m, ref):
+    refp = dict(ref.named_parameters())
+    pv = torch.cat([p.detach().reshape(-1).cpu() for _, p in m.named_parameters()])
+    rv = torch.cat([refp[n].detach().reshape(-1) for n, _ in m.named_parameters()])
+    return pv, rv
+
+
+def _lsce(o, t):
+    from oracle import ref_ops as R
+    return R.label_smoothing_ce(o, t, 0.1)
+
+
+# ------------------------------------------------------------------------------------------ knowledge distillation
+@pytest.mark.parametrize("student,pool", [("vit_tiny_patch16_224", "avg"), ("deit_tiny_distilled_patch16_224", "token")])
+def test_kd_workload_matches_oracle(device, student, pool):
+    """StudentWithDistillation(student, frozen ViT teacher) + DistillationLoss(LabelSmoothingCE(0.1), alpha 0.7, T 4)
+    through train_one_epoch for two optimizer steps, against the oracle's restatement of both classes in the oracle's
+    loop.  Also test_kd.py's contract: a tuple in train mode, one tensor in eval mode, no gradient for the teacher."""
+    from oracle import ref_engine
+    from vision_transformers_torch_xla_amd import engine, optim_factory
+    from vision_transformers_torch_xla_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy, StudentWithDistillation
+    ref_s, s = _pair(student, device, depth=2, global_pool=pool, seed=0)
+    ref_t, t = _pair("vit_small_patch16_224", device, depth=2, global_pool="avg", seed=7)
+    for teacher in (ref_t, t):                               # main.py:737-741
+        teacher.eval()
+        for p in teacher.parameters():
+            p.requires_grad = False
+    t_before = t._flat["p"].clone()
+    model, rmodel = StudentWithDistillation(s, t), ref_engine.RefStudentWithDistillation(ref_s, ref_t)
+    crit = DistillationLoss(LabelSmoothingCrossEntropy(0.1), 0.7, 4.0)
+    rcrit = ref_engine.RefDistillationLoss(_lsce, 0.7, 4.0)
+    B, steps = 4, 2
+    data = [_batch(B, 224, 40, 300 + i) for i in range(steps)]
+
+    # the wrapper's contract (test_kd.py:103-120)
+    model.train()
+    out = model(data[0][0].to(device))
+    assert isinstance(out, tuple) and len(out) == 2 and out[0].requires_grad and not out[1].requires_grad
+    model.eval()
+    with torch.no_grad():
+        assert isinstance(model(data[0][0].to(device)), torch.Tensor)
+
+    opt = optim_factory.create_optimizer(_Args, s)           # the student is what is optimised (main.py:866-869)
+    ropt = ref_engine.make_optimizer(ref_s, 1e-3, 0.05)
+    want = ref_engine.ref_train_one_epoch(rmodel, rcrit, data, ropt, 0, None, None, steps, 1, forward_kwargs=dict(emulate=True))
+    got = engine.train_one_epoch(model, crit, data, opt, device, 0, None, 0, None, None, num_training_steps_per_epoch=steps,
+                                 update_freq=1, log_freq=1)
+    print(f"KD {student}: HIP {got} oracle {want}")
+    assert set(got) == {"loss", "lr", "class_acc"}
+    assert abs(got["loss"] - want["loss"]) <= E2E_TOL * abs(want["loss"])
+    assert abs(got["class_acc"] - want["class_acc"]) <= 1e-6
+    pv, rv = _weights(s, ref_s)
+    print(f"   student weights after {steps} steps rel {rel_l2(pv, rv):.2e}")
+    assert rel_l2(pv, rv) <= WEIGHT_TOL
+    assert torch.equal(t._flat["p"], t_before)               # the teacher is untouched
+    assert all(p.grad is None for p in t.parameters())
+
+
+def test_kd_loss_gradient_matches_autograd(device):
+    """the fused criterion on identical logits: value and d/d(student logits) against autograd through the oracle's formula"""
+    from oracle import ref_ops as R
+    from vision_transformers_torch_xla_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy
+    g = torch.Generator().manual_seed(4)
+    s0, t0 = 3 * torch.randn(16, 1000, generator=g), 3 * torch.randn(16, 1000, generator=g)
+    y = torch.randint(0, 1000, (16,), generator=g)
+    sr = s0.clone().requires_grad_(True)
+    want = R.distillation_loss(sr, t0, y, _lsce, 0.7, 4.0)
+    want.backward()
+    sg = s0.clone().to(device).requires_grad_(True)
+    got = DistillationLoss(LabelSmoothingCrossEntropy(0.1), 0.7, 4.0)((sg, t0.to(device)), y.to(device))
+    got.backward()
+    assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item())
+    assert rel_l2(sg.grad, sr.grad) <= 1e-5
+
+
+# --------------------------------------------------------------------------------------------------------- EMA
+def test_model_ema_built_after_a_training_step(device):
+    """ModelEma deep-copies the model: the copy must work after the model has run a training forward / backward with
+    stochastic depth (pinned-table ring with events, side stream), share nothing with it, and follow
+    ema = decay * ema + (1 - decay) * model on every entry of the state dict."""
+    from oracle.ref_vit import create_ref_model
+    from vision_transformers_torch_xla_amd import optim_factory, utils
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    ref, m = _pair("vit_tiny_patch16_224", device, depth=2, dpr=0.3)
+    opt = optim_factory.create_optimizer(_Args, m)
+    crit = LabelSmoothingCrossEntropy(0.1)
+    x, y = _batch(8, 224, 40, 21)
+    m.train()
+
+    def step():
+        crit(m(x.to(device)), y.to(device)).backward()
+        opt.step()
+        opt.zero_grad()
+
+    torch.manual_seed(0)
+    step()
+    ema = utils.ModelEma(m, decay=0.9)
+    assert not ema.ema.training and all(not p.requires_grad for p in ema.ema.parameters())
+    assert torch.equal(ema.ema._flat["p"], m._flat["p"]) and ema.ema._flat["p"].data_ptr() != m._flat["p"].data_ptr()
+    assert ema.ema._flat["g"] is None                         # an averaged copy never trains: no gradient buffer
+    e = {k: v.detach().clone() for k, v in ema.ema.state_dict().items()}
+    for _ in range(3):
+        step()
+        ema.update(m)
+        e = {k: 0.9 * e[k] + (1.0 - 0.9) * v.detach() for k, v in m.state_dict().items()}
+    for k, v in ema.ema.state_dict().items():
+        assert rel_l2(v, e[k]) <= 1e-6, k
+    # the averaged copy evaluates like the oracle with the averaged weights
+    ref2 = create_ref_model("vit_tiny_patch16_224", num_classes=40, global_pool="avg", depth=2)
+    ref2.load_state_dict({k: v.cpu() for k, v in ema.ema.state_dict().items()})
+    ref2.eval()
+    with torch.no_grad():
+        assert rel_l2(ema.ema(x.to(device)), ref2(x, emulate=True)) <= E2E_TOL
+
+
+class _SnapshotLoader:
+    """yields the batches and records the model's weights whenever the loop asks for the next one (= after every step)"""
+
+    def __init__(self, data, model):
+        self.data, self.model, self.snaps = data, model, []
+
+    def __iter__(self):
+        for b in self.data:
+            self.snaps.append(self.model._flat["p"].clone())
+            yield b
+        self.snaps.append(self.model._flat["p"].clone())
+
+
+def test_train_one_epoch_with_ema_clip_and_accumulation(device):
+    """train_one_epoch(max_norm=1, model_ema=..., update_freq=2): 4 micro-batches = 2 optimizer steps.  Against the oracle's
+    loop with torch.nn.utils.clip_grad_norm_ and its own EMA; and the EMA against the exact recurrence over the HIP model's
+    own weights after each optimizer step."""
+    from oracle import ref_engine, ref_ops as R
+    from vision_transformers_torch_xla_amd import engine, optim_factory, utils
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    ref, m = _pair("vit_tiny_patch16_224", device, depth=2)
+    B, micro, uf = 4, 4, 2
+    data = [_batch(B, 224, 40, 400 + i) for i in range(micro)]
+    lr_sched = R.cosine_scheduler(1e-3, 1e-6, 2, micro // uf, warmup_epochs=1, start_warmup_value=2e-4)
+    wd_sched = R.cosine_scheduler(0.05, 0.01, 2, micro // uf)
+    opt = optim_factory.create_optimizer(_Args, m)
+    ropt = ref_engine.make_optimizer(ref, 1e-3, 0.05)
+    ema, rema = utils.ModelEma(m, decay=0.5), ref_engine.RefModelEma(ref, decay=0.5)
+    norms = []
+    want = ref_engine.ref_train_one_epoch(ref, _lsce, data, ropt, 0, lr_sched, wd_sched, micro // uf, uf, forward_kwargs=dict(emulate=True),
+                                          max_norm=1.0, model_ema=rema,
+                                          record=lambda i, o, l, mod: norms.append(torch.cat([p.grad.reshape(-1) for p in mod.parameters()]).norm().item()))
+    assert min(norms[uf - 1::uf]) > 1.5                       # the clip is active in every optimizer step of this test
+    loader = _SnapshotLoader(data, m)
+    got = engine.train_one_epoch(m, LabelSmoothingCrossEntropy(0.1), loader, opt, device, 0, None, 1.0, ema, None,
+                                 start_steps=0, lr_schedule_values=lr_sched, wd_schedule_values=wd_sched,
+                                 num_training_steps_per_epoch=micro // uf, update_freq=uf, log_freq=1)
+    print(f"clip + EMA + update_freq=2: HIP {got} oracle {want}; oracle gradient norms before clipping {norms}")
+    assert abs(got["loss"] - want["loss"]) <= E2E_TOL * abs(want["loss"])          # engine.py:268,294: the logged loss is loss / update_freq
+    assert abs(got["lr"] - want["lr"]) <= 1e-12 and abs(got["class_acc"] - want["class_acc"]) <= 1e-6
+    pv, rv = _weights(m, ref)
+    ev, erv = _weights(ema.ema, rema.ema)
+    print(f"   weights rel {rel_l2(pv, rv):.2e}, EMA weights rel {rel_l2(ev, erv):.2e}")
+    assert rel_l2(pv, rv) <= WEIGHT_TOL and rel_l2(ev, erv) <= WEIGHT_TOL
+    # weights change only on the last micro-step of an accumulation group; the EMA follows exactly those weights
+    s = loader.snaps
+    assert len(s) == micro + 1 and torch.equal(s[0], s[1]) and torch.equal(s[2], s[3]) and not torch.equal(s[1], s[2])
+    e = s[0]
+    for after_step in (s[2], s[4]):
+        e = 0.5 * e + 0.5 * after_step
+    assert rel_l2(ema.ema._flat["p"], e) <= 1e-6
+
+
+def test_clip_grad_norm_matches_torch(device):
+    """engine.clip_grad_norm_ on the flat gradient buffer = torch.nn.utils.clip_grad_norm_ on the same gradients"""
+    from vision_transformers_torch_xla_amd import engine
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    _, m = _pair("vit_tiny_patch16_224", device, depth=2)
+    x, y = _batch(4, 224, 40, 31)
+    m.train()
+    for max_norm in (0.5, 1e6):                               # clipping / not clipping
+        m.zero_grad()
+        LabelSmoothingCrossEntropy(0.1)(m(x.to(device)), y.to(device)).backward()
+        clones = [p.grad.detach().clone().requires_grad_(False) for p in m.parameters()]
+        holders = [torch.nn.Parameter(torch.zeros_like(c)) for c in clones]
+        for h, c in zip(holders, clones):
+            h.grad = c
+        want_norm = torch.nn.utils.clip_grad_norm_(holders, max_norm)
+        got_norm = engine.clip_grad_norm_(m, max_norm)
+        assert abs(got_norm.item() - want_norm.item()) <= 1e-5 * want_norm.item()
+        got = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        want = torch.cat([h.grad.reshape(-1) for h in holders])
+        assert rel_l2(got, want) <= 1e-6
+        if max_norm > 1e5:
+            assert torch.equal(got, torch.cat([c.reshape(-1) for c in clones]))     # below the bound nothing is touched
+
+
+def test_accumulated_micro_batches_equal_the_concatenated_batch(device):
+    """update_freq = 2 (loss / 2 per micro-batch, engine.py:268) gives the gradient of one step on the concatenated batch"""
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    _, m = _pair("vit_tiny_patch16_224", device, depth=2)
+    x, y = _batch(8, 224, 40, 41)
+    x, y = x.to(device), y.to(device)
+    crit = LabelSmoothingCrossEntropy(0.1)
+    m.train()
+    m.zero_grad()
+    crit(m(x), y).backward()
+    whole = m._flat["g"].clone()
+    m.zero_grad()
+    for a in (slice(0, 4), slice(4, 8)):
+        (crit(m(x[a]), y[a]) / 2).backward()
+    e = rel_l2(m._flat["g"], whole)
+    print(f"accumulated vs concatenated gradient rel {e:.2e}")
+    assert e <= 1e-3
+
+
+# ------------------------------------------------------------------------ the CPU-runnable configuration, full size
+def test_vit_tiny_batch64_full_depth_three_steps(device):
+    """The reference's CPU-runnable case (ViT-Tiny/16, 64 images of 224 px, all 12 blocks, timm initialisation, drop_path 0.1)
+    for three optimizer steps of train_one_epoch against the CPU oracle's loop.  The stochastic-depth factors are drawn
+    once and used by both sides in every step (the two sides draw from different generators otherwise)."""
+    from oracle import ref_engine, ref_ops as R
+    from oracle.ref_vit import create_ref_model
+    from vision_transformers_torch_xla_amd import engine, optim_factory
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+    torch.manual_seed(0)
+    ref = create_ref_model("vit_tiny_patch16_224", num_classes=1000, global_pool="avg", drop_path_rate=0.1)
+    m = create_model("vit_tiny_patch16_224", pretrained=False, num_classes=1000, global_pool="avg", drop_path_rate=0.1)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(device)
+    assert sum(p.numel() for p in m.parameters()) == 5_717_416
+    B, steps = 64, 3
+    data = [_batch(B, 224, 1000, 500 + i) for i in range(steps)]
+    ref.train()
+    scales = ref.make_drop_scales(B, generator=torch.Generator().manual_seed(8))
+    m._forced_drop_scales = scales
+    lr_sched = R.cosine_scheduler(4e-3, 1e-6, 2, steps, warmup_epochs=1)
+    wd_sched = R.cosine_scheduler(0.05, 0.05, 2, steps)
+    opt = optim_factory.create_optimizer(_Args, m)
+    ropt = ref_engine.make_optimizer(ref, 4e-3, 0.05)
+    losses = []
+    want = ref_engine.ref_train_one_epoch(ref, _lsce, data, ropt, 0, lr_sched, wd_sched, steps, 1,
+                                          forward_kwargs=dict(emulate=True, drop_scales=scales), record=lambda i, o, l, mod: losses.append(l))
+    got = engine.train_one_epoch(m, LabelSmoothingCrossEntropy(0.1), data, opt, device, 0, None, 0, None, None, start_steps=0,
+                                 lr_schedule_values=lr_sched, wd_schedule_values=wd_sched, num_training_steps_per_epoch=steps,
+                                 update_freq=1, log_freq=1)
+    pv, rv = _weights(m, ref)
+    print(f"ViT-Tiny B=64 depth 12, 3 steps: HIP {got} oracle {want} (oracle losses {losses}); weights rel {rel_l2(pv, rv):.2e}")
+    assert abs(got["loss"] - want["loss"]) <= E2E_TOL * abs(want["loss"])
+    assert abs(got["lr"] - want["lr"]) <= 1e-12
+    assert abs(got["class_acc"] - want["class_acc"]) <= 1.0 / B + 1e-9        # 192 argmax decisions over 1000 near-tied classes at init
+    assert rel_l2(pv, rv) <= 5e-3
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+def _ck_args(tmp, **kw):
+    a = argparse.Namespace(output_dir=str(tmp), save_ckpt_num=3, save_ckpt_freq=1, auto_resume=True, resume="", model_ema=True,
+                           eval=False, start_epoch=0, opt="adamw", lr=1e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=None)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_resume_is_bit_identical_to_the_uninterrupted_run(device, tmp_path):
+    """two steps, save_model, a fresh model / optimizer / EMA, auto_load_model, a third step: parameters, both Adam moments
+    and the EMA weights have the bits of the run that never stopped (utils/__init__.py:686-770)"""
+    from vision_transformers_torch_xla_amd import optim_factory, utils
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+    crit = LabelSmoothingCrossEntropy(0.1)
+    data = [tuple(t.to(device) for t in _batch(6, 224, 40, 600 + i)) for i in range(3)]
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        m = create_model("vit_tiny_patch16_224", num_classes=40, global_pool="avg", depth=3, drop_path_rate=0.2).to(device)
+        m.train()
+        return m, optim_factory.create_optimizer(_Args, m), utils.ModelEma(m, decay=0.9)
+
+    def step(m, opt, ema, i):
+        torch.manual_seed(100 + i)                            # the host-side stochastic-depth draws of step i
+        crit(m(data[i][0]), data[i][1]).backward()
+        opt.step()
+        opt.zero_grad()
+        ema.update(m)
+
+    m, opt, ema = fresh(0)
+    for i in range(2):
+        step(m, opt, ema, i)
+    args = _ck_args(tmp_path)
+    utils.save_model(args, 0, m, m, opt, None, model_ema=ema)
+    step(m, opt, ema, 2)
+
+    m2, opt2, ema2 = fresh(1)                                 # other initial weights: everything must come from the file
+    args2 = _ck_args(tmp_path)
+    utils.auto_load_model(args2, m2, m2, opt2, None, model_ema=ema2)
+    assert args2.start_epoch == 1 and opt2._steps == 2
+    step(m2, opt2, ema2, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(m2._flat["p"], m._flat["p"])
+    assert torch.equal(opt2._m, opt._m) and torch.equal(opt2._v, opt._v)
+    assert torch.equal(ema2.ema._flat["p"], ema.ema._flat["p"])
+    assert torch.equal(m2._flat["b"], m._flat["b"])           # the bf16 copies the GEMMs read
+
+
+def test_finetune_224_to_384_then_train(device, tmp_path):
+    """a 224 px checkpoint initialises a 384 px model with another head (main.py:653-674 + the position-table resample), and
+    the loaded model takes a training step that matches the oracle loaded with the same state"""
+    from oracle.ref_vit import create_ref_model
+    from vision_transformers_torch_xla_amd import optim_factory, utils
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+    torch.manual_seed(0)
+    src = create_model("vit_tiny_patch16_224", num_classes=24, global_pool="avg", depth=1)
+    torch.save({"model": src.state_dict()}, tmp_path / "pre.pth")
+    dst = create_model("vit_tiny_patch16_224", num_classes=16, global_pool="avg", depth=1, img_size=384).to(device)
+    missing, unexpected = utils.load_finetune_checkpoint(dst, tmp_path / "pre.pth")
+    assert sorted(missing) == ["head.bias", "head.weight"] and unexpected == []
+    assert dst._views_ok() and dst.pos_embed.shape == (1, 577, 192)
+    assert torch.equal(dst.blocks[0].mlp.fc1.weight.cpu(), src.blocks[0].mlp.fc1.weight)
+    ref = create_ref_model("vit_tiny_patch16_224", num_classes=16, global_pool="avg", depth=1, img_size=384)
+    ref.load_state_dict({k: v.cpu() for k, v in dst.state_dict().items()})
+    x, y = _batch(2, 384, 16, 51)
+    ref.train(); dst.train()
+    from oracle import ref_ops as R
+    R.label_smoothing_ce(ref(x, emulate=True), y, 0.1).backward()
+    opt = optim_factory.create_optimizer(_Args, dst)
+    loss = LabelSmoothingCrossEntropy(0.1)(dst(x.to(device)), y.to(device))
+    loss.backward()
+    refp = dict(ref.named_parameters())
+    gv = torch.cat([p.grad.reshape(-1).cpu() for _, p in dst.named_parameters()])
+    rv = torch.cat([refp[n].grad.reshape(-1) for n, _ in dst.named_parameters()])
+    print(f"384 px fine-tune step: gradient rel {rel_l2(gv, rv):.2e}")
+    assert rel_l2(gv, rv) <= 3e-2
+    opt.step()
+    assert all(torch.isfinite(p).all() for p in dst.parameters())

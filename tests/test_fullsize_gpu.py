@@ -1,5 +1,7 @@
-"""The kernels at the sizes of the headline workload (ViT-B/16, 224 px, 512 images per GPU: M = 100 864 token rows), checked
-through properties that need no full-size CPU run:
+"""The kernels at the full sizes of the benchmark workloads - ViT-B/16 224 px at 512 images per GPU (M = 100 864 token rows,
+D = 768, 12 heads, F = 3072), ViT-L/16 224 px at 256 images (M = 50 432, D = 1024, 16 heads, F = 4096: 3.08 tile rounds of the
+persistent GEMM, 4 096 heads of attention) and ViT-B/16 384 px at 128 images (577 tokens per image, M = 73 856) - checked through
+properties that need no full-size CPU run:
 
   * sampled rows / entries against an fp64 product of exactly those rows (the CPU oracle's arithmetic on a sample),
   * linearity of the weight-gradient GEMM over a split of the token rows, its bias gradient against column sums,
@@ -16,8 +18,15 @@ from tests.util import rel_l2
 pytestmark = pytest.mark.gpu
 
 bf16, f32 = torch.bfloat16, torch.float32
-B, NTOK, D, H, F = 512, 197, 768, 12, 3072
-M = B * NTOK
+# name -> (images, tokens per image, width, heads, MLP width, model, image size)
+CONFIGS = {"vitb224": (512, 197, 768, 12, 3072, "vit_base_patch16_224", 224),
+           "vitl224": (256, 197, 1024, 16, 4096, "vit_large_patch16_224", 224),
+           "vitb384": (128, 577, 768, 12, 3072, "vit_base_patch16_384", 384)}
+
+
+@pytest.fixture(params=list(CONFIGS))
+def cfg(request):
+    return CONFIGS[request.param]
 
 
 def _ops():
@@ -29,9 +38,12 @@ def _rand(shape, gen, device, scale=1.0):
     return (torch.randn(shape, generator=gen, device=device) * scale).to(bf16)
 
 
-@pytest.mark.parametrize("N,K,epi", [(2304, 768, "bias"), (768, 3072, "res"), (3072, 768, "gelu"), (768, 2304, "plain")])
-def test_gemm_nt_full_size_sampled_rows(device, N, K, epi):
+@pytest.mark.parametrize("shape,epi", [("qkv", "bias"), ("fc2", "res"), ("fc1", "gelu"), ("dqkv", "plain")])
+def test_gemm_nt_full_size_sampled_rows(device, cfg, shape, epi):
     from oracle import ref_ops as R
+    B, NTOK, D, H, F = cfg[:5]
+    M = B * NTOK
+    N, K = {"qkv": (3 * D, D), "fc2": (D, F), "fc1": (F, D), "dqkv": (D, 3 * D)}[shape]
     from vision_transformers_torch_xla_amd import _lib
     ops = _ops()
     g = torch.Generator(device=device).manual_seed(N + K)
@@ -59,16 +71,19 @@ def test_gemm_nt_full_size_sampled_rows(device, N, K, epi):
     assert torch.isfinite(out.float()).all()
 
 
-@pytest.mark.parametrize("N,K", [(2304, 768), (768, 768), (3072, 768), (768, 3072)])
-def test_gemm_tn_full_size_linearity_and_bias(device, N, K):
+@pytest.mark.parametrize("shape", ["qkv", "proj", "fc1", "fc2"])
+def test_gemm_tn_full_size_linearity_and_bias(device, cfg, shape):
     ops = _ops()
+    B, NTOK, D, H, F = cfg[:5]
+    M = B * NTOK
+    N, K = {"qkv": (3 * D, D), "proj": (D, D), "fc1": (F, D), "fc2": (D, F)}[shape]
     g = torch.Generator(device=device).manual_seed(3 * N + K)
     a, b = _rand((M, N), g, device), _rand((M, K), g, device)
     whole = torch.empty((N, K), device=device)
     db = torch.empty(N, device=device)
     ops.gemm_tn(a, b, whole, dbias=db)
     # contraction rows split at an odd place: the two partial products must add up to the whole one
-    cut = 197 * 211 + 5
+    cut = NTOK * (B // 2 - 45) + 5
     parts = torch.empty((N, K), device=device)
     dbp = torch.empty(N, device=device)
     ops.gemm_tn(a[:cut], b[:cut], parts, dbias=dbp)
@@ -77,7 +92,7 @@ def test_gemm_tn_full_size_linearity_and_bias(device, N, K):
     assert rel_l2(parts, whole) <= 2e-6
     assert rel_l2(dbp, db) <= 2e-6
     assert rel_l2(db.cpu(), a.double().sum(0).float().cpu()) <= 1e-5
-    # sampled entries against fp64 dot products over all 100 864 rows
+    # sampled entries against fp64 dot products over all token rows
     ni, ki = torch.randint(0, N, (48,)), torch.randint(0, K, (48,))
     want = (a[:, ni.to(device)].double() * b[:, ki.to(device)].double()).sum(0)
     assert rel_l2(whole[ni.to(device), ki.to(device)].cpu(), want.float().cpu()) <= 1e-5
@@ -86,8 +101,10 @@ def test_gemm_tn_full_size_linearity_and_bias(device, N, K):
     assert torch.equal(again, whole)                      # fixed summation order, with or without the bias gradient
 
 
-def test_attention_full_size_constant_keys(device):
+def test_attention_full_size_constant_keys(device, cfg):
     ops = _ops()
+    B, NTOK, D, H, F = cfg[:5]
+    M = B * NTOK
     g = torch.Generator(device=device).manual_seed(7)
     qkv = _rand((M, 3 * D), g, device)
     kconst = _rand((1, D), g, device)
@@ -114,8 +131,10 @@ def test_attention_full_size_constant_keys(device):
     assert torch.isfinite(dqkv.float()).all()
 
 
-def test_layernorm_full_size_row_properties(device):
+def test_layernorm_full_size_row_properties(device, cfg):
     ops = _ops()
+    B, NTOK, D, H, F = cfg[:5]
+    M = B * NTOK
     g = torch.Generator(device=device).manual_seed(9)
     x = _rand((M, D), g, device, 3.0) + 1.5
     ones, zeros = torch.ones(D, device=device), torch.zeros(D, device=device)
@@ -139,20 +158,21 @@ def test_layernorm_full_size_row_properties(device):
     assert rel_l2(dgamma.cpu(), (dy.double() * xhat.double()).sum(0).float().cpu()) <= 1e-4
 
 
-def test_training_steps_full_size_are_reproducible(device):
-    """Two runs of two steps of the benchmark workload from the same state: same loss bits, same parameter bits (every
+def test_training_steps_full_size_are_reproducible(device, cfg):
+    """Two runs of two steps of a benchmark workload from the same state: same loss bits, same parameter bits (every
     reduction in the step has a fixed order; stochastic-depth draws follow torch.manual_seed)."""
+    B, name, size = cfg[0], cfg[5], cfg[6]
     from vision_transformers_torch_xla_amd import optim_factory
     from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
     from vision_transformers_torch_xla_amd.vit import create_model
 
     g = torch.Generator(device=device).manual_seed(0)
-    x = torch.randn(B, 3, 224, 224, generator=g, device=device)
+    x = torch.randn(B, 3, size, size, generator=g, device=device)
     t = torch.randint(0, 1000, (B,), generator=g, device=device)
 
     def run():
         torch.manual_seed(0)
-        m = create_model("vit_base_patch16_224", pretrained=False, num_classes=1000, global_pool="avg", drop_path_rate=0.1).to(device)
+        m = create_model(name, pretrained=False, num_classes=1000, global_pool="avg", drop_path_rate=0.1).to(device)
         m.train()
 
         class A:
