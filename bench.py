@@ -31,9 +31,7 @@ except ValueError:
 import torch
 import torch.distributed as dist
 
-FLOP_PER_IMAGE = {"vit_base_patch16_224": 105.38e9}          # train = 6 x forward MACs, GEMM + attention contractions
-GEMM_FLOP_PER_IMAGE = {"vit_base_patch16_224": 101.09e9}     # the linears/patch/head share (attention products: 4.29e9)
-NT_TRAFFIC_BYTES_PER_LAUNCH = 1.14e9     # 2 x 383.9e6 (FETCH_SIZE) + 372.2e6 (WRITE_SIZE), profiles/r1_pmc_hbm.md
+PMC_HBM_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_hbm.json")
 PEAK_BF16_TFLOPS = 2500.0                                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                                        # HBM3E spec (6.3 TB/s measured achievable, same guide)
 
@@ -65,14 +63,23 @@ class SyntheticLoader:
             self.prof_switch(False)
 
 
-def cpu_baseline(batch=32, steps=3, threads=None):
-    """The oracle's reference-semantics fp32 train step (engine.py:257-274 restated) on this box's host cores."""
+def train_macs_per_image(model):
+    """forward multiply-accumulates per image of the GEMM / attention contractions: (patch embedding + head, attention branch of
+    one block, MLP branch of one block).  Training work = 6 x (fwd 2, data gradient 2, weight gradient 2 flop per MAC)."""
+    N, D, L = model.num_tokens, model.embed_dim, model.depth
+    F = model.blocks[0].mlp.fc1.out_features
+    heads = 2 if model.distilled else 1
+    fixed = model.num_patches * (model.in_chans * model.patch_size ** 2) * D + heads * D * model.num_classes
+    attn = N * D * 3 * D + N * D * D + 2 * N * N * D
+    mlp = 2 * N * D * F
+    return fixed, attn, mlp, L
+
+
+def _cpu_steps(name, batch, steps, threads):
     from oracle import ref_engine, ref_ops
     from oracle.ref_vit import create_ref_model
-    threads = threads or min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
-    model = create_ref_model("vit_base_patch16_224", num_classes=1000, global_pool="avg", drop_path_rate=0.1)
+    model = create_ref_model(name, num_classes=1000, global_pool="avg", drop_path_rate=0.1)
     opt = ref_engine.make_optimizer(model, 4e-3, 0.05)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(batch, 3, 224, 224, generator=g)
@@ -81,9 +88,44 @@ def cpu_baseline(batch=32, steps=3, threads=None):
     ref_engine.ref_train_one_epoch(model, crit, [(x, y)], opt)                      # warm-up
     t0 = time.time()
     ref_engine.ref_train_one_epoch(model, crit, [(x, y)] * steps, opt)
-    dt = time.time() - t0
-    return {"value": batch * steps / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"ViT-B/16 224px fp32 CPU oracle train step (fwd+bwd+AdamW), batch {batch}, {steps} timed steps after 1 warm-up"}
+    return batch * steps / (time.time() - t0)
+
+
+def cpu_baseline(batch=32, steps=3, threads=None):
+    """The oracle's reference-semantics fp32 train step (engine.py:257-274 restated) on this box's host cores: the headline
+    model on a bounded sample, and the reference's own CPU-runnable case (ViT-Tiny/16, 64 images per step) beside it."""
+    threads = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    out = {"value": _cpu_steps("vit_base_patch16_224", batch, steps, threads), "unit": "images/s", "cores": threads, "kind": "port",
+           "sample": f"ViT-B/16 224px fp32 CPU oracle train step (fwd+bwd+AdamW), batch {batch}, {steps} timed steps after 1 warm-up"}
+    out["vit_tiny_batch64"] = {"value": _cpu_steps("vit_tiny_patch16_224", 64, 3, threads), "unit": "images/s",
+                               "sample": "ViT-Tiny/16 224px fp32, batch 64, 3 timed steps after 1 warm-up (the reference's CPU-runnable configuration)"}
+    return out
+
+
+def pmc_traffic(args):
+    if args.model == "vit_base_patch16_224" and args.batch == 512 and os.path.exists(PMC_HBM_FILE):
+        try:
+            rec = json.load(open(PMC_HBM_FILE))["gemm_nt"]
+            return {"traffic": rec["bytes_per_launch"], "traffic_unit": f"bytes/launch (algorithmic: {rec['algorithmic_bytes_per_launch']:.3g}); "
+                                                                        f"{rec['source']}"}
+        except (KeyError, ValueError) as e:
+            log(f"[bench] {PMC_HBM_FILE}: {e!r}")
+    return {"traffic": None, "traffic_unit": "bytes/launch"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a child process (this
+    process never touches the GPU), pass its stdout - rank 0's JSON line - through, and leave with its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}")
+    raise SystemExit(subprocess.run(cmd).returncode)
 
 
 def main():
@@ -97,6 +139,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-every", type=int, default=5, help="bracket the kernel launches of every n-th timed step with HIP events")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
 
     # stdout carries the one JSON line and nothing else: everything a library prints there (RCCL writes a version banner to
     # stdout under NCCL_DEBUG=VERSION) goes to stderr instead, at the file-descriptor level
@@ -111,7 +157,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+        raise SystemExit(f"[bench] WORLD_SIZE={world} does not match --gpus {args.gpus}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...), or run "
+                         f"`python bench.py --gpus {args.gpus}` without a launcher and it starts the ranks itself")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernels are the only implementation of the hot path")
     # Rehearsal switches for a box with fewer GPUs than ranks (never set by the driver): VITK_SHARE_GPU=1 puts every rank
@@ -130,6 +178,9 @@ def main():
             dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
         else:
             dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
+        if dist.get_world_size() != args.gpus and not force_dist:
+            raise SystemExit(f"[bench] process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    n_ranks = dist.get_world_size() if dist.is_initialized() else 1
 
     from vision_transformers_torch_xla_amd import engine, ops, optim_factory, utils
     from vision_transformers_torch_xla_amd.dp import DistributedDataParallel
@@ -161,6 +212,7 @@ def main():
                                           num_training_steps_per_epoch=nsteps, update_freq=1, log_freq=10)
 
     run(args.warmup, 0)
+    core._branch_samples[:] = [0, 0, 0, 0]
     want_roof = not args.no_roofline and args.prof_every > 0
     if want_roof:
         ops.prof_reset()
@@ -184,6 +236,11 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
+        fixed, attn, mlp, L = train_macs_per_image(core)
+        flop_img = 6.0 * (fixed + L * (attn + mlp))                     # the reference's work: every branch for every sample
+        st = core._branch_samples                                      # stochastic depth: branches run for their kept samples only
+        fa, fm = (st[0] / st[1], st[2] / st[3]) if st[1] and st[3] else (1.0, 1.0)
+        flop_img_exec = 6.0 * (fixed + L * (attn * fa + mlp * fm))
         result = {
             "metric": "images/sec (whole node) ViT-B/16 224px bf16", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -192,7 +249,13 @@ def main():
                                    f"224x224 synthetic randn batches resident in HBM, drop_path 0.1",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "loss_last": stats.get("loss")},
-            "step_tflops_per_gpu": round(FLOP_PER_IMAGE.get(args.model, 0) * args.batch / (ms * 1e-3) / 1e12, 1),
+            # ranks of the process group the gradient all-reduce ran in (RCCL unless a rehearsal chose gloo); 0 = no group
+            "ranks": n_ranks, "rccl_ranks": n_ranks if (dist.is_initialized() and backend == "nccl") else 0,
+            # algorithmic = 6 x forward MACs for every sample and branch (what the reference computes); executed = without the
+            # residual branches that stochastic depth dropped and this implementation therefore never ran
+            "step_tflops_per_gpu": round(flop_img * args.batch / (ms * 1e-3) / 1e12, 1),
+            "step_tflops_per_gpu_executed": round(flop_img_exec * args.batch / (ms * 1e-3) / 1e12, 1),
+            "gflop_per_image": {"algorithmic": round(flop_img / 1e9, 2), "executed": round(flop_img_exec / 1e9, 2)},
         }
         if want_roof:
             nt_ms, nt_fl, nt_n = ops.prof_read(ops.PROF_GEMM_NT)
@@ -202,11 +265,10 @@ def main():
                 "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 # HBM-side bytes per launch (average over this kernel family's launches of a step), from two separate
-                # rocprofv3 --pmc passes over this same command (FETCH_SIZE doubled as gfx950 needs, + WRITE_SIZE):
-                # profiles/r1_pmc_hbm.md.  Counters cannot be read from inside the process, so this is the committed
-                # measurement for the default workload and null for anything else.
-                "traffic": NT_TRAFFIC_BYTES_PER_LAUNCH if (args.model == "vit_base_patch16_224" and args.batch == 512) else None,
-                "traffic_unit": "bytes/launch (algorithmic: 8.14e8)",
+                # rocprofv3 --pmc passes over this same command (FETCH_SIZE doubled as gfx950 needs, + WRITE_SIZE), written
+                # to profiles/pmc_hbm.json by tools/pmc_hbm.sh + tools/summarize_pmc_hbm.py.  Counters cannot be read from
+                # inside the process, so this is the committed measurement for the default workload, null for any other.
+                **pmc_traffic(args),
                 "kernel": "gemm_ntp_kernel / gemm_nt_kernel (bf16 MFMA 16x16x32; all epilogue instantiations: forward linears + data gradients)",
                 "launches": nt_n, "avg_launch_ms": round(nt_ms / max(nt_n, 1), 4),
                 "flop_per_launch_avg": round(nt_fl / max(nt_n, 1) / 1e9, 2),

@@ -259,6 +259,7 @@ class VisionTransformer(nn.Module):
         self._forced_drop_scales = None      # tests inject per-layer DropPath factors here
         self._compact_droppath = os.environ.get("VITK_DROPPATH_COMPACT", "1") != "0"   # compute a branch for its kept samples only
         self._pin_ring = _PinRing()
+        self._branch_samples = [0, 0, 0, 0]  # samples a residual branch was computed for / could have been (benchmark accounting)
         self._bwd_taps = None                # tests: dict that receives per-layer intermediate gradients
         self._grad_ready_hook = None         # data-parallel reducer: called with the flat offset below which grads are final
         self._ws = ops.Workspace()
@@ -469,6 +470,9 @@ class VisionTransformer(nn.Module):
         rates = [blk.drop_path if self.training else 0.0 for blk in self.blocks]
         active = [i for i, r in enumerate(rates) if r > 0.0]
         out = [(None, None)] * self.depth
+        st = self._branch_samples          # [attention computed, attention total, MLP computed, MLP total] since the last reset
+        st[1] += B * self.depth; st[3] += B * self.depth
+        st[0] += B * (self.depth - len(active)); st[2] += B * (self.depth - len(active))
         if not active:
             return out
         keep = torch.tensor([1.0 - rates[i] for i in active for _ in range(2)], dtype=f32)          # [2A]
@@ -476,6 +480,8 @@ class VisionTransformer(nn.Module):
         plans = _Branch.from_masks(mask, keep, device, self._compact_droppath, self._pin_ring)
         for k, i in enumerate(active):
             out[i] = (plans[2 * k], plans[2 * k + 1])
+            st[0] += plans[2 * k].nk if plans[2 * k].compact else B
+            st[2] += plans[2 * k + 1].nk if plans[2 * k + 1].compact else B
         return out
 
     def forward(self, x: torch.Tensor):
