@@ -192,5 +192,16 @@ def test_metric_logger_semantics():
     ml.synchronize_between_processes()                     # single process: no-op
     with pytest.raises(AttributeError):
         ml.nope
+    # window statistics: the latest `window_size` values; median = the lower middle one (torch.median); totals over everything
+    sv = utils.SmoothedValue(window_size=4, fmt="{median:.1f}|{avg:.2f}|{max:.0f}|{value:.0f}|{global_avg:.3f}")
+    for v in (9.0, 1.0, 4.0, 2.0, 8.0):
+        sv.update(v)
+    want = torch.tensor([1.0, 4.0, 2.0, 8.0])
+    assert sv.median == want.median().item() == 2.0 and sv.avg == want.mean().item() and sv.max == 8.0 and sv.value == 8.0
+    assert sv.count == 5 and sv.total == 24.0 and str(sv) == "2.0|3.75|8|8|4.800"
+    sv.count, sv.total = 10, 5.0                           # the cross-rank sum assigns them
+    assert sv.global_avg == 0.5
+    with pytest.raises(TypeError):
+        ml.update(loss="high")
     top1, top5 = utils.accuracy(torch.tensor([[0.1, 0.9, 0.0, 0.2, 0.3, 0.4, 0.5], [0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.0]]), torch.tensor([1, 6]), (1, 5))
     assert top1.item() == 50.0 and top5.item() == 50.0

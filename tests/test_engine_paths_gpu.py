@@ -237,6 +237,27 @@ def test_accumulated_micro_batches_equal_the_concatenated_batch(device):
     assert e <= 1e-3
 
 
+def test_metric_logger_keeps_device_scalars_on_the_gpu(device):
+    """meters take 0-d GPU tensors without a host sync and fetch all of them together when they are read"""
+    from vision_transformers_torch_xla_amd import utils
+    ml = utils.MetricLogger(delimiter="  ")
+    vals = [0.5, 2.0, 3.5]
+    for v in vals:
+        ml.update(loss=torch.tensor(v, device=device))
+        ml.meters["class_acc"].update(torch.tensor(v / 4, device=device), n=8)
+        ml.update(lr=0.1)
+    assert len(ml.meters["loss"]._pending) == 3 and ml.meters["loss"]._seen == 0      # nothing fetched yet
+    ml.flush()
+    assert not ml.meters["loss"]._pending and not ml.meters["class_acc"]._pending
+    assert ml.loss.count == 3 and ml.loss.global_avg == 2.0 and ml.loss.value == 3.5 and ml.loss.median == 2.0
+    assert ml.meters["class_acc"].count == 24 and abs(ml.meters["class_acc"].global_avg - 0.5) < 1e-7
+    ml.update(loss=torch.tensor(6.0, device=device))
+    assert ml.loss.global_avg == 3.0                       # a read resolves what is pending
+    ml.update(loss=torch.tensor(1.0, device=device))
+    ml.update(loss=9.0)                                    # host value after a device value: order is kept
+    assert ml.loss.value == 9.0 and ml.loss.count == 6
+
+
 # ------------------------------------------------------------------------ the CPU-runnable configuration, full size
 def test_vit_tiny_batch64_full_depth_three_steps(device):
     """The reference's CPU-runnable case (ViT-Tiny/16, 64 images of 224 px, all 12 blocks, timm initialisation, drop_path 0.1)

@@ -42,26 +42,6 @@ def clip_grad_norm_(model, max_norm: float):
     return core._sumsq.sqrt()[0]
 
 
-class _DeferredMeters:
-    """Collects device scalars and resolves them with one host sync per flush instead of one per step."""
-
-    def __init__(self, logger, flush_every=64):
-        self.logger, self.flush_every, self.items = logger, flush_every, []
-
-    def add(self, name, tensor, n=1):
-        self.items.append((name, tensor.detach().reshape(()).float(), n))
-        if len(self.items) >= self.flush_every:
-            self.flush()
-
-    def flush(self):
-        if not self.items:
-            return
-        vals = torch.stack([t for _, t, _ in self.items]).tolist()
-        for (name, _, n), v in zip(self.items, vals):
-            self.logger.meters[name].update(v, n=n)
-        self.items = []
-
-
 def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loader: Iterable,
                     optimizer: torch.optim.Optimizer, device: torch.device, epoch: int, loss_scaler=None, max_norm: float = 0,
                     model_ema=None, mixup_fn=None, log_writer=None, wandb_logger=None, start_steps=None,
@@ -72,8 +52,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     start_steps = start_steps or 0
     if log_writer is not None and num_training_steps_per_epoch is not None:
         log_writer.set_step(epoch * num_training_steps_per_epoch * update_freq)
-    metric_logger = utils.MetricLogger(delimiter="  ")
-    deferred = _DeferredMeters(metric_logger)
+    metric_logger = utils.MetricLogger(delimiter="  ")      # device scalars stay on the GPU until the meters are read
     header = f"Epoch: [{epoch}]"
     reducer = getattr(model, "reducer", None)
     optimizer.zero_grad()
@@ -119,17 +98,15 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             class_acc = (ops.argmax_rows(out0.detach().float()) == targets).float().mean()
 
         if data_iter_step % log_freq == 0 or data_iter_step < 5:
-            deferred.add("loss", loss)
+            metric_logger.update(loss=loss.detach())
             if class_acc is not None:
-                deferred.add("class_acc", class_acc, n=samples.size(0))
+                metric_logger.meters["class_acc"].update(class_acc, n=samples.size(0))
             metric_logger.update(lr=optimizer.param_groups[0]["lr"])
-        if log_writer is not None or wandb_logger is not None:
-            deferred.flush()
+        if log_writer is not None:          # a per-step host log is the caller's choice: it costs one sync per step
             lv = metric_logger.meters["loss"].value if metric_logger.meters["loss"].count else float("nan")
-            if log_writer is not None:
-                log_writer.update(loss=lv, lr=optimizer.param_groups[0]["lr"])
+            log_writer.update(loss=lv, lr=optimizer.param_groups[0]["lr"])
 
-    deferred.flush()
+    metric_logger.flush()
     if "loss" in metric_logger.meters and not math.isfinite(metric_logger.meters["loss"].global_avg):
         print("Loss is {}, stopping training".format(metric_logger.meters["loss"].global_avg))
         sys.exit(1)
@@ -143,7 +120,6 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
 def evaluate(data_loader, model, device, use_amp=False, tpu: bool = False):
     criterion = CrossEntropyLoss()
     metric_logger = utils.MetricLogger(delimiter="  ")
-    deferred = _DeferredMeters(metric_logger)
     model.eval()
     for batch in data_loader:
         images, target = batch[0], batch[-1]
@@ -153,10 +129,10 @@ def evaluate(data_loader, model, device, use_amp=False, tpu: bool = False):
         loss = criterion(output, target)
         acc1, acc5 = utils.accuracy(output, target, topk=(1, 5))
         bs = images.shape[0]
-        deferred.add("loss", loss)
-        deferred.add("acc1", acc1, n=bs)
-        deferred.add("acc5", acc5, n=bs)
-    deferred.flush()
+        metric_logger.update(loss=loss)
+        metric_logger.meters["acc1"].update(acc1, n=bs)
+        metric_logger.meters["acc5"].update(acc5, n=bs)
+    metric_logger.flush()
     metric_logger.synchronize_between_processes()
     if utils.is_main_process() and metric_logger.meters:
         print("* Acc@1 {top1.global_avg:.3f} Acc@5 {top5.global_avg:.3f} loss {losses.global_avg:.3f}".format(

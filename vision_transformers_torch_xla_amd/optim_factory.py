@@ -29,26 +29,25 @@ class LayerDecayValueAssigner(object):
 
 
 def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None):
-    parameter_group_names = {}
-    parameter_group_vars = {}
+    """The optimizer's parameter groups, with the reference's membership rule (optim_factory.py:151-195): a trainable
+    parameter is exempt from weight decay when it is a vector (norm scales, biases), is named "*.bias", or is listed in
+    `skip_list` (the model's no_weight_decay() names); everything else decays with `weight_decay`.  With `get_num_layer`
+    the two classes are further split per layer id and each group carries get_layer_scale(layer id) as "lr_scale" (1.0
+    otherwise).  Groups are returned in the order their first parameter appears in model.named_parameters(), parameters in
+    that order within a group - the order optimizer state dicts are indexed by."""
+    groups = {}
     for name, param in model.named_parameters():
         if not param.requires_grad:
             continue
-        if len(param.shape) == 1 or name.endswith(".bias") or name in skip_list:
-            group_name, this_weight_decay = "no_decay", 0.0
-        else:
-            group_name, this_weight_decay = "decay", weight_decay
-        layer_id = None
-        if get_num_layer is not None:
-            layer_id = get_num_layer(name)
-            group_name = "layer_%d_%s" % (layer_id, group_name)
-        if group_name not in parameter_group_names:
-            scale = get_layer_scale(layer_id) if get_layer_scale is not None else 1.0
-            parameter_group_names[group_name] = {"weight_decay": this_weight_decay, "params": [], "lr_scale": scale}
-            parameter_group_vars[group_name] = {"weight_decay": this_weight_decay, "params": [], "lr_scale": scale}
-        parameter_group_vars[group_name]["params"].append(param)
-        parameter_group_names[group_name]["params"].append(name)
-    return list(parameter_group_vars.values())
+        exempt = param.ndim == 1 or name.endswith(".bias") or name in skip_list
+        layer = get_num_layer(name) if get_num_layer is not None else None
+        key = ("no_decay" if exempt else "decay") if layer is None else "layer_%d_%s" % (layer, "no_decay" if exempt else "decay")
+        group = groups.get(key)
+        if group is None:
+            group = groups[key] = {"weight_decay": 0.0 if exempt else weight_decay, "params": [],
+                                   "lr_scale": get_layer_scale(layer) if get_layer_scale is not None else 1.0}
+        group["params"].append(param)
+    return list(groups.values())
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -197,26 +196,21 @@ class FusedAdamW(torch.optim.Optimizer):
 
 
 def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):
-    opt_lower = args.opt.lower()
-    weight_decay = args.weight_decay
+    """args.opt / lr / weight_decay / opt_eps / opt_betas -> optimizer, with the reference's call contract
+    (optim_factory.py:214-296).  filter_bias_and_bn: decay lives in the parameter groups (the exempt group gets 0), so the
+    optimizer-wide default is 0; otherwise one group over all parameters with args.weight_decay.  An "a_b_adamw" style name
+    selects by its last part.  AdamW - the only optimizer the reference's recipes use (main.py:171) - is the fused one."""
     if filter_bias_and_bn:
-        skip = {}
-        if skip_list is not None:
-            skip = skip_list
-        elif hasattr(model, "no_weight_decay"):
-            skip = model.no_weight_decay()
-        parameters = get_parameter_groups(model, weight_decay, skip, get_num_layer, get_layer_scale)
-        weight_decay = 0.0
+        exempt_names = skip_list if skip_list is not None else (model.no_weight_decay() if hasattr(model, "no_weight_decay") else ())
+        params = get_parameter_groups(model, args.weight_decay, exempt_names, get_num_layer, get_layer_scale)
+        default_decay = 0.0
     else:
-        parameters = model.parameters()
-    opt_args = dict(lr=args.lr, weight_decay=weight_decay)
-    if getattr(args, "opt_eps", None) is not None:
-        opt_args["eps"] = args.opt_eps
-    if getattr(args, "opt_betas", None) is not None:
-        opt_args["betas"] = tuple(args.opt_betas)
-    opt_split = opt_lower.split("_")
-    opt_lower = opt_split[-1]
-    if opt_lower in ("adamw", "fusedadamw"):
-        flat_model = model if hasattr(model, "_flat") else None
-        return FusedAdamW(parameters, model=flat_model, **opt_args)
-    raise VitkError(f"optimizer {args.opt!r} is not implemented: the ViT recipes of the reference use adamw (main.py:171)")
+        params, default_decay = model.parameters(), args.weight_decay
+    hyper = {"lr": args.lr, "weight_decay": default_decay}
+    for attr, key, conv in (("opt_eps", "eps", float), ("opt_betas", "betas", tuple)):
+        if getattr(args, attr, None) is not None:
+            hyper[key] = conv(getattr(args, attr))
+    kind = args.opt.lower().split("_")[-1]
+    if kind not in ("adamw", "fusedadamw"):
+        raise VitkError(f"optimizer {args.opt!r} is not implemented: the ViT recipes of the reference use adamw (main.py:171)")
+    return FusedAdamW(params, model=model if hasattr(model, "_flat") else None, **hyper)

@@ -11,7 +11,7 @@ import datetime
 import math
 import os
 import time
-from collections import defaultdict, deque
+from collections import defaultdict
 
 import numpy as np
 import torch
@@ -34,145 +34,229 @@ def is_main_process():
     return get_rank() == 0
 
 
-class SmoothedValue(object):
-    """Window median/average plus global average of a series (utils/__init__.py:103-191)."""
+class SmoothedValue:
+    """Statistics of one scalar series with the attribute names the reference's meter has (utils/__init__.py:103-191):
+    `median`, `avg`, `max`, `value` over the latest `window_size` values, `global_avg` = total / count over everything
+    (`update(value, n)` adds value * n to `total` and n to `count`), `fmt` for printing.
+
+    Built for a loop that must not stop the GPU: `update` also takes a 0-d device tensor and keeps it as it is; pending
+    device scalars are fetched together - one stack, one copy - when a statistic is read, when `resolve()` is called, or
+    when PENDING_LIMIT of them have piled up.  The window is a fixed ring of floats."""
+
+    PENDING_LIMIT = 256
 
     def __init__(self, window_size=20, fmt=None):
-        if fmt is None:
-            fmt = "{median:.4f} ({global_avg:.4f})"
-        self.deque = deque(maxlen=window_size)
-        self.total = 0.0
-        self.count = 0
-        self.fmt = fmt
+        self.fmt = "{median:.4f} ({global_avg:.4f})" if fmt is None else fmt
+        self._ring = np.zeros(max(int(window_size), 1), dtype=np.float64)
+        self._seen = 0                      # values pushed so far; the ring holds the last min(_seen, size) of them
+        self._count, self._total = 0, 0.0
+        self._pending = []                  # (0-d device tensor, n) in arrival order
 
+    # -- writing
     def update(self, value, n=1):
-        self.deque.append(value)
-        self.count += n
-        self.total += value * n
-
-    def synchronize_between_processes(self):
-        """SUM of [count, total] over ranks; the window is not synchronised (utils/__init__.py:122-142)."""
-        if not is_dist_avail_and_initialized():
+        if isinstance(value, torch.Tensor) and value.is_cuda:
+            self._pending.append((value.detach().reshape(()).to(torch.float32), n))
+            if len(self._pending) >= self.PENDING_LIMIT:
+                self.resolve()
             return
-        dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == "nccl") else torch.device("cpu")
-        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
-        dist.barrier()
-        dist.all_reduce(t)
-        t = t.tolist()
-        self.count = int(t[0])
-        self.total = t[1]
+        if self._pending:
+            self.resolve()                  # keep the series in arrival order
+        self._push(float(value), n)
+
+    def _push(self, v, n):
+        self._ring[self._seen % len(self._ring)] = v
+        self._seen += 1
+        self._count += n
+        self._total += v * n
+
+    def resolve(self, values=None):
+        """Move the pending device scalars into the statistics (`values`: their host values when a caller fetched them
+        together with other meters')."""
+        if not self._pending:
+            return
+        if values is None:
+            values = torch.stack([t for t, _ in self._pending]).tolist()
+        pending, self._pending = self._pending, []
+        for (_, n), v in zip(pending, values):
+            self._push(v, n)
+
+    # -- the totals are plain attributes to callers (cross-rank sync and checkpoint code assign them)
+    @property
+    def count(self):
+        self.resolve()
+        return self._count
+
+    @count.setter
+    def count(self, v):
+        self.resolve()
+        self._count = v
+
+    @property
+    def total(self):
+        self.resolve()
+        return self._total
+
+    @total.setter
+    def total(self, v):
+        self.resolve()
+        self._total = v
+
+    def _window(self):
+        self.resolve()
+        k = min(self._seen, len(self._ring))
+        if k == 0:
+            raise ValueError("SmoothedValue: no values yet")
+        return self._ring[:k]
 
     @property
     def median(self):
-        return torch.tensor(list(self.deque)).median().item()
+        w = np.sort(self._window())
+        return float(w[(len(w) - 1) // 2])          # the lower middle value, as torch.median picks it
 
     @property
     def avg(self):
-        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+        return float(self._window().mean())
+
+    @property
+    def max(self):
+        return float(self._window().max())
+
+    @property
+    def value(self):
+        self.resolve()
+        if self._seen == 0:
+            raise ValueError("SmoothedValue: no values yet")
+        return float(self._ring[(self._seen - 1) % len(self._ring)])
 
     @property
     def global_avg(self):
         return self.total / self.count
 
-    @property
-    def max(self):
-        return max(self.deque)
-
-    @property
-    def value(self):
-        return self.deque[-1]
+    def synchronize_between_processes(self):
+        """count and total become their sums over all ranks; the window stays local (utils/__init__.py:122-142)"""
+        if not is_dist_avail_and_initialized():
+            return
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=_collective_device())
+        dist.barrier()
+        dist.all_reduce(t)
+        c, tot = t.tolist()
+        self._count, self._total = int(c), tot
 
     def __str__(self):
         return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
 
 
-class MetricLogger(object):
+def _collective_device():
+    """where a small tensor must live to be all-reduced: the current GPU under RCCL, the host otherwise"""
+    if torch.cuda.is_available() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+class MetricLogger:
+    """Named SmoothedValue meters, created on first use (`logger.meters[name]`, `logger.update(name=value)`, `logger.name`),
+    printed as "name: meter" joined by `delimiter` (utils/__init__.py:194-275).  Device scalars handed to `update` stay on
+    the GPU until `flush()` - or any read - fetches ALL meters' pending values in one transfer; the cross-rank sync is one
+    packed fp64 all-reduce for every meter instead of a barrier + all-reduce per meter (the sums are the same)."""
+
     def __init__(self, delimiter="\t"):
         self.meters = defaultdict(SmoothedValue)
         self.delimiter = delimiter
 
-    def update(self, **kwargs):
-        for k, v in kwargs.items():
+    def update(self, **named_values):
+        for name, v in named_values.items():
             if v is None:
                 continue
             if isinstance(v, torch.Tensor):
-                v = v.item()
-            assert isinstance(v, (float, int))
-            self.meters[k].update(v)
-
-    def __getattr__(self, attr):
-        if attr in self.meters:
-            return self.meters[attr]
-        if attr in self.__dict__:
-            return self.__dict__[attr]
-        raise AttributeError("'{}' object has no attribute '{}'".format(type(self).__name__, attr))
-
-    def __str__(self):
-        return self.delimiter.join("{}: {}".format(name, str(meter)) for name, meter in self.meters.items())
-
-    def synchronize_between_processes(self):
-        """One packed fp64 all-reduce for all meters (the reference does one barrier + all_reduce per meter;
-        the sums are identical)."""
-        if not is_dist_avail_and_initialized() or not self.meters:
-            return
-        names = sorted(self.meters)
-        dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == "nccl") else torch.device("cpu")
-        t = torch.tensor([[self.meters[n].count, self.meters[n].total] for n in names], dtype=torch.float64, device=dev)
-        dist.all_reduce(t)
-        for n, (c, tot) in zip(names, t.tolist()):
-            self.meters[n].count = int(c)
-            self.meters[n].total = tot
+                if v.numel() != 1:
+                    raise TypeError(f"MetricLogger.update({name}=...): expected a scalar, got shape {tuple(v.shape)}")
+                if not v.is_cuda:
+                    v = v.item()
+            elif not isinstance(v, (int, float, np.integer, np.floating)):
+                raise TypeError(f"MetricLogger.update({name}=...): expected a number or a 0-d tensor, got {type(v).__name__}")
+            self.meters[name].update(v)
 
     def add_meter(self, name, meter):
         self.meters[name] = meter
 
+    def flush(self):
+        """one device -> host transfer for every pending scalar of every meter"""
+        waiting = [(m, len(m._pending)) for m in self.meters.values() if m._pending]
+        if not waiting:
+            return
+        flat = torch.stack([t for m, _ in waiting for t, _ in m._pending]).tolist()
+        at = 0
+        for m, k in waiting:
+            m.resolve(flat[at:at + k])
+            at += k
+
+    def __getattr__(self, name):
+        meters = self.__dict__.get("meters")
+        if meters is not None and name in meters:
+            return meters[name]
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    def __str__(self):
+        self.flush()
+        return self.delimiter.join(f"{name}: {meter}" for name, meter in self.meters.items())
+
+    def synchronize_between_processes(self):
+        self.flush()
+        if not is_dist_avail_and_initialized() or not self.meters:
+            return
+        names = sorted(self.meters)                      # the same order on every rank
+        packed = torch.tensor([[self.meters[n].count, self.meters[n].total] for n in names], dtype=torch.float64, device=_collective_device())
+        dist.all_reduce(packed)
+        for n, (c, tot) in zip(names, packed.tolist()):
+            self.meters[n].count, self.meters[n].total = int(c), tot
+
     def log_every(self, iterable, print_freq, header=None):
-        i = 0
+        """iterate, timing the loop body ("time") and the wait for the next item ("data"); a status line every `print_freq` items"""
         header = header or ""
-        start_time = time.time()
-        end = time.time()
-        iter_time = SmoothedValue(fmt="{avg:.4f}")
-        data_time = SmoothedValue(fmt="{avg:.4f}")
-        n = len(iterable) if hasattr(iterable, "__len__") else None
-        for obj in iterable:
-            data_time.update(time.time() - end)
-            yield obj
-            iter_time.update(time.time() - end)
-            if print_freq and (i % print_freq == 0 or (n is not None and i == n - 1)):
-                if n is not None:
-                    eta = str(datetime.timedelta(seconds=int(iter_time.global_avg * (n - i))))
-                    print(self.delimiter.join([header, f"[{i}/{n}]", f"eta: {eta}", str(self), f"time: {iter_time}", f"data: {data_time}"]))
-                else:
-                    print(self.delimiter.join([header, f"[{i}]", str(self), f"time: {iter_time}", f"data: {data_time}"]))
-            i += 1
-            end = time.time()
-        total_time = time.time() - start_time
-        print("{} Total time: {} ({:.4f} s / it)".format(header, str(datetime.timedelta(seconds=int(total_time))), total_time / max(i, 1)))
+        length = len(iterable) if hasattr(iterable, "__len__") else None
+        per_item, waiting = SmoothedValue(fmt="{avg:.4f}"), SmoothedValue(fmt="{avg:.4f}")
+        began = mark = time.time()
+        seen = 0
+        for seen, item in enumerate(iterable, 1):
+            waiting.update(time.time() - mark)
+            yield item
+            per_item.update(time.time() - mark)
+            i = seen - 1
+            if print_freq and (i % print_freq == 0 or i + 1 == length):
+                fields = [header, f"[{i}/{length}]" if length is not None else f"[{i}]"]
+                if length is not None:
+                    fields.append("eta: " + str(datetime.timedelta(seconds=int(per_item.global_avg * (length - i)))))
+                print(self.delimiter.join(fields + [str(self), f"time: {per_item}", f"data: {waiting}"]))
+            mark = time.time()
+        spent = time.time() - began
+        print(f"{header} Total time: {datetime.timedelta(seconds=int(spent))} ({spent / max(seen, 1):.4f} s / it)")
 
 
 def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1):
-    """Linear warm-up then half-cosine, one value per iteration (utils/__init__.py:667-684)."""
-    warmup_schedule = np.array([])
-    warmup_iters = warmup_epochs * niter_per_ep
-    if warmup_steps > 0:
-        warmup_iters = warmup_steps
-    if warmup_epochs > 0:
-        warmup_schedule = np.linspace(start_warmup_value, base_value, warmup_iters)
-    iters = np.arange(epochs * niter_per_ep - warmup_iters)
-    schedule = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / (len(iters)))) for i in iters])
-    schedule = np.concatenate((warmup_schedule, schedule))
-    assert len(schedule) == epochs * niter_per_ep
+    """One value per training iteration: a linear ramp start_warmup_value -> base_value over the warm-up iterations
+    (warmup_steps > 0 overrides warmup_epochs * niter_per_ep for its LENGTH, but the ramp only exists when
+    warmup_epochs > 0), then half a cosine from base_value to final_value over what is left (utils/__init__.py:667-684;
+    the values are np.array_equal to the reference's, hence math.cos per element and the same expression order)."""
+    total = epochs * niter_per_ep
+    ramp_len = warmup_steps if warmup_steps > 0 else warmup_epochs * niter_per_ep
+    ramp = np.linspace(start_warmup_value, base_value, ramp_len) if warmup_epochs > 0 else np.array([])
+    tail_len = total - ramp_len
+    tail = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / tail_len)) for i in range(tail_len)])
+    schedule = np.concatenate((ramp, tail))
+    if len(schedule) != total:
+        # the reference asserts the same condition
+        raise AssertionError(f"cosine_scheduler: {len(schedule)} values for {total} iterations (warm-up longer than the run, or warmup_steps without warmup_epochs)")
     return schedule
 
 
 def accuracy(output, target, topk=(1,)):
-    """timm.utils.accuracy: top-k accuracy in percent (engine.py:405)."""
-    maxk = min(max(topk), output.size()[1])
-    batch_size = target.size(0)
-    _, pred = output.topk(maxk, 1, True, True)
-    pred = pred.t()
-    correct = pred.eq(target.reshape(1, -1).expand_as(pred))
-    return [correct[:min(k, maxk)].reshape(-1).float().sum(0) * 100.0 / batch_size for k in topk]
+    """Top-k accuracy in percent, one 0-d tensor per k (timm.utils.accuracy as engine.py:405 calls it): the share of rows
+    whose target is among the k largest logits."""
+    widest = min(max(topk), output.shape[1])
+    best = output.topk(widest, dim=1).indices                    # [B, widest], largest first
+    hit = best == target.reshape(-1, 1)
+    rows = target.shape[0]
+    return [hit[:, :min(k, widest)].any(dim=1).float().sum() * 100.0 / rows for k in topk]
 
 
 def init_distributed_mode(args=None, backend=None):
