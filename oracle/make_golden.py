@@ -12,6 +12,10 @@ Contents (all float32 unless noted):
                          x [4,3,224,224] is NOT stored (regenerated from the seed: torch.Generator().manual_seed(1));
                          stores targets, logits (fp32 path), logits_emul (bf16-emulating path), loss, loss_emul,
                          per-parameter gradient norms and three full small gradients, weights-after-one-AdamW-step digests
+  vit_tiny_d2_train3.npz the same model through the loop restatement (engine.py:257-299) for 3 consecutive optimizer steps on batches
+                         seeded 11, 12, 13 (B = 4), AdamW lr 1e-3 -> cosine schedule with one warm-up epoch, wd 0.05: per step logits
+                         and loss (fp32 and bf16-emulating paths), per-parameter gradient norms of step 1, the two parameter groups'
+                         member names, the returned {loss, lr, class_acc}, first / last values of both schedules, weight norms at the end
   schedules.npz          cosine_scheduler lr / wd values (utils/__init__.py:667-684 semantics) for two configurations
   ops.npz                single-op vectors: LayerNorm, exact GELU, attention (3 heads x 17 tokens) forward and backward,
                          label-smoothing / soft-target / KD losses with their logits gradients
@@ -70,6 +74,46 @@ def gen_step():
     np.savez_compressed(OUT / "vit_tiny_d2_step.npz", **out)
 
 
+TRAIN3_SEEDS = (11, 12, 13)
+
+
+def train3_schedules():
+    return (R.cosine_scheduler(1e-3, 1e-6, 2, 3, warmup_epochs=1, start_warmup_value=1e-4), R.cosine_scheduler(0.05, 0.02, 2, 3))
+
+
+def gen_train3():
+    torch.set_num_threads(1)
+    out = {}
+    data = [tiny_batch(seed=s) for s in TRAIN3_SEEDS]
+    lr_sched, wd_sched = train3_schedules()
+    out["lr_schedule"], out["wd_schedule"] = lr_sched, wd_sched
+    out["targets"] = np.stack([y.numpy() for _, y in data])
+    for tag, emu in (("", False), ("_emul", True)):
+        m = tiny_model()
+        opt = ref_engine.make_optimizer(m, 1e-3, 0.05)
+        logits, losses, gnorms = [], [], []
+
+        def record(i, output, loss_value, model):
+            logits.append(output.detach().numpy().copy())
+            losses.append(loss_value)
+            if i == 0:
+                gnorms.extend(p.grad.norm().item() for p in model.parameters())
+        stats = ref_engine.ref_train_one_epoch(m, lambda o, t: R.label_smoothing_ce(o, t, 0.1), data, opt, 0, lr_sched, wd_sched, 3, 1,
+                                               forward_kwargs=dict(emulate=emu), record=record)
+        out["logits" + tag] = np.stack(logits)
+        out["losses" + tag] = np.array(losses, dtype=np.float64)
+        out["grad_norms_step1" + tag] = np.array(gnorms, dtype=np.float64)
+        out["stats" + tag] = np.array([stats["loss"], stats["lr"], stats["class_acc"]], dtype=np.float64)
+        out["weight_norms_end" + tag] = np.array([p.detach().norm().item() for p in m.parameters()], dtype=np.float64)
+        if not emu:
+            groups = R.parameter_groups(m, 0.05, m.no_weight_decay())
+            out["param_names"] = np.array([n for n, _ in m.named_parameters()])
+            out["group_weight_decay"] = np.array([g["weight_decay"] for g in groups])
+            for gi, g in enumerate(groups):
+                out[f"group{gi}_names"] = np.array(g["names"])
+    np.savez_compressed(OUT / "vit_tiny_d2_train3.npz", **out)
+
+
 def gen_schedules():
     np.savez_compressed(
         OUT / "schedules.npz",
@@ -112,6 +156,7 @@ def gen_ops():
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     gen_step()
+    gen_train3()
     gen_schedules()
     gen_ops()
     for f in sorted(OUT.glob("*.npz")):

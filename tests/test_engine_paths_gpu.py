@@ -237,6 +237,43 @@ def test_accumulated_micro_batches_equal_the_concatenated_batch(device):
     assert e <= 1e-3
 
 
+def test_three_steps_against_the_committed_fixture(device):
+    """tests/golden/vit_tiny_d2_train3.npz (written by oracle/make_golden.py): three consecutive optimizer steps of the 2-block
+    ViT-Tiny through train_one_epoch - per-step logits and loss, the parameter groups, the returned dict and the weights at
+    the end against the stored bf16-emulating oracle run (and the fp32 run at the same end-to-end bar)"""
+    from pathlib import Path
+    import numpy as np
+    from oracle.make_golden import TRAIN3_SEEDS, tiny_batch, tiny_model
+    from vision_transformers_torch_xla_amd import engine, optim_factory
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+    gold = np.load(Path(__file__).resolve().parent / "golden" / "vit_tiny_d2_train3.npz")
+    m = create_model("vit_tiny_patch16_224", num_classes=40, global_pool="avg", depth=2)
+    m.load_state_dict(tiny_model().state_dict())               # the fixture's seeded initial state
+    m = m.to(device)
+    data = [tiny_batch(seed=s) for s in TRAIN3_SEEDS]
+    opt = optim_factory.create_optimizer(_Args, m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert [[names[id(p)] for p in g["params"]] for g in opt.param_groups] == [list(gold["group0_names"]), list(gold["group1_names"])]
+    assert [g["weight_decay"] for g in opt.param_groups] == list(gold["group_weight_decay"])
+    crit = LabelSmoothingCrossEntropy(0.1)
+    seen = []
+
+    def recording(o, t):
+        seen.append(o.detach().float().cpu().numpy())
+        return crit(o, t)
+    got = engine.train_one_epoch(m, recording, data, opt, device, 0, None, 0, None, None, start_steps=0, lr_schedule_values=gold["lr_schedule"],
+                                 wd_schedule_values=gold["wd_schedule"], num_training_steps_per_epoch=3, update_freq=1, log_freq=1)
+    for tag in ("_emul", ""):
+        errs = [rel_l2(torch.from_numpy(a), torch.from_numpy(b)) for a, b in zip(seen, gold["logits" + tag])]
+        print(f"fixture{tag or '_fp32'}: per-step logits rel {[f'{e:.1e}' for e in errs]}, loss {got['loss']:.6f} vs {gold['stats' + tag][0]:.6f}")
+        assert max(errs) <= E2E_TOL
+        assert abs(got["loss"] - gold["stats" + tag][0]) <= E2E_TOL * gold["stats" + tag][0]
+        assert abs(got["lr"] - gold["stats" + tag][1]) <= 1e-12 and abs(got["class_acc"] - gold["stats" + tag][2]) <= 1e-6
+        wn = np.array([p.detach().norm().item() for p in m.parameters()])
+        assert np.allclose(wn, gold["weight_norms_end" + tag], rtol=2e-3)
+
+
 def test_metric_logger_keeps_device_scalars_on_the_gpu(device):
     """meters take 0-d GPU tensors without a host sync and fetch all of them together when they are read"""
     from vision_transformers_torch_xla_amd import utils

@@ -66,51 +66,155 @@ def test_oracle_matches_stock_torch_composition(pool):
         assert rel_l2(a, b) < 2e-5, n
 
 
-def test_oracle_matches_huggingface_vit():
-    transformers = pytest.importorskip("transformers")
-    from transformers import ViTConfig, ViTModel
-    torch.manual_seed(1)
-    ref = create_ref_model("vit_tiny_patch16_224", num_classes=40, global_pool="token", depth=2)
-    cfg = ViTConfig(hidden_size=192, num_hidden_layers=2, num_attention_heads=3, intermediate_size=768, hidden_act="gelu",
-                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-6, image_size=224, patch_size=16,
-                    num_channels=3, qkv_bias=True)
-    hf = ViTModel(cfg, add_pooling_layer=False).eval()
+def _hf_config(cls, depth=2, **kw):
+    return cls(hidden_size=192, num_hidden_layers=depth, num_attention_heads=3, intermediate_size=768, hidden_act="gelu",
+               hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, layer_norm_eps=1e-6, image_size=224, patch_size=16,
+               num_channels=3, qkv_bias=True, **kw)
+
+
+def _copy_into_hf(hf, ref, prefix=""):
+    """the oracle's weights into a Hugging Face ViT / DeiT encoder (module names of transformers 4 and 5).  Returns
+    {oracle parameter name: [hf parameter names whose gradients, concatenated along dim 0, are its gradient]}."""
     sd = hf.state_dict()
-    D = 192
-    def put(k, v):
+    D = ref.embed_dim
+    back = {}
+
+    def put(k, v, name, part=False):
+        k = prefix + k
         assert k in sd and sd[k].shape == v.shape, (k, tuple(v.shape))
         sd[k] = v.detach().clone()
-    put("embeddings.cls_token", ref.cls_token); put("embeddings.position_embeddings", ref.pos_embed)
-    put("embeddings.patch_embeddings.projection.weight", ref.patch_embed.proj.weight)
-    put("embeddings.patch_embeddings.projection.bias", ref.patch_embed.proj.bias)
-    new_names = "layers.0.attention.q_proj.weight" in sd       # transformers >= 5 renamed the ViT sub-modules
+        back.setdefault(name, []).append(k)
+
+    put("embeddings.cls_token", ref.cls_token, "cls_token")
+    put("embeddings.position_embeddings", ref.pos_embed, "pos_embed")
+    if ref.distilled:
+        put("embeddings.distillation_token", ref.dist_token, "dist_token")
+    put("embeddings.patch_embeddings.projection.weight", ref.patch_embed.proj.weight, "patch_embed.proj.weight")
+    put("embeddings.patch_embeddings.projection.bias", ref.patch_embed.proj.bias, "patch_embed.proj.bias")
+    new_names = prefix + "layers.0.attention.q_proj.weight" in sd       # transformers >= 5 renamed the sub-modules
     for i, blk in enumerate(ref.blocks):
-        wq, wk, wv = blk.attn.qkv.weight.split(D, 0)
-        bq, bk, bv = blk.attn.qkv.bias.split(D, 0)
         if new_names:
             p = f"layers.{i}."
-            names = dict(q="attention.q_proj", k="attention.k_proj", v="attention.v_proj", o="attention.o_proj",
-                         fc1="mlp.fc1", fc2="mlp.fc2")
+            names = dict(q="attention.q_proj", k="attention.k_proj", v="attention.v_proj", o="attention.o_proj", fc1="mlp.fc1", fc2="mlp.fc2")
         else:
             p = f"encoder.layer.{i}."
             names = dict(q="attention.attention.query", k="attention.attention.key", v="attention.attention.value",
                          o="attention.output.dense", fc1="intermediate.dense", fc2="output.dense")
-        for nm, w_, b_ in (("q", wq, bq), ("k", wk, bk), ("v", wv, bv)):
-            put(p + names[nm] + ".weight", w_); put(p + names[nm] + ".bias", b_)
-        put(p + names["o"] + ".weight", blk.attn.proj.weight); put(p + names["o"] + ".bias", blk.attn.proj.bias)
-        put(p + "layernorm_before.weight", blk.norm1.weight); put(p + "layernorm_before.bias", blk.norm1.bias)
-        put(p + "layernorm_after.weight", blk.norm2.weight); put(p + "layernorm_after.bias", blk.norm2.bias)
-        put(p + names["fc1"] + ".weight", blk.mlp.fc1.weight); put(p + names["fc1"] + ".bias", blk.mlp.fc1.bias)
-        put(p + names["fc2"] + ".weight", blk.mlp.fc2.weight); put(p + names["fc2"] + ".bias", blk.mlp.fc2.bias)
-    put("layernorm.weight", ref.norm.weight); put("layernorm.bias", ref.norm.bias)
+        b = f"blocks.{i}."
+        for nm, w_, b_ in zip("qkv", blk.attn.qkv.weight.split(D, 0), blk.attn.qkv.bias.split(D, 0)):      # rows [q ; k ; v]
+            put(p + names[nm] + ".weight", w_, b + "attn.qkv.weight"); put(p + names[nm] + ".bias", b_, b + "attn.qkv.bias")
+        put(p + names["o"] + ".weight", blk.attn.proj.weight, b + "attn.proj.weight"); put(p + names["o"] + ".bias", blk.attn.proj.bias, b + "attn.proj.bias")
+        put(p + "layernorm_before.weight", blk.norm1.weight, b + "norm1.weight"); put(p + "layernorm_before.bias", blk.norm1.bias, b + "norm1.bias")
+        put(p + "layernorm_after.weight", blk.norm2.weight, b + "norm2.weight"); put(p + "layernorm_after.bias", blk.norm2.bias, b + "norm2.bias")
+        put(p + names["fc1"] + ".weight", blk.mlp.fc1.weight, b + "mlp.fc1.weight"); put(p + names["fc1"] + ".bias", blk.mlp.fc1.bias, b + "mlp.fc1.bias")
+        put(p + names["fc2"] + ".weight", blk.mlp.fc2.weight, b + "mlp.fc2.weight"); put(p + names["fc2"] + ".bias", blk.mlp.fc2.bias, b + "mlp.fc2.bias")
+    if hasattr(ref, "norm"):
+        put("layernorm.weight", ref.norm.weight, "norm.weight"); put("layernorm.bias", ref.norm.bias, "norm.bias")
     hf.load_state_dict(sd)
-    x, _ = tiny_batch()
-    ref.eval()
+    return back
+
+
+def _perturbed(name, pool, seed, **kw):
+    torch.manual_seed(seed)
+    ref = create_ref_model(name, num_classes=40, global_pool=pool, depth=2, **kw)
     with torch.no_grad():
-        feats = hf(pixel_values=x).last_hidden_state[:, 0]
-        want = F.linear(feats, ref.head.weight, ref.head.bias)
-        got = ref(x)
+        for p in ref.parameters():
+            p.add_(0.05 * torch.randn_like(p))          # biases, tokens and norm offsets away from their zero / one init
+    return ref
+
+
+def _check_grads_against_hf(ref, hf, back, skip=()):
+    hfp = dict(hf.named_parameters())
+    worst = 0.0
+    for n, p in ref.named_parameters():
+        if n in skip:
+            continue
+        want = torch.cat([hfp[k].grad for k in back[n]], 0)
+        e = rel_l2(p.grad, want)
+        worst = max(worst, e)
+        assert e < 5e-5, (n, e)
+    return worst
+
+
+def test_oracle_matches_huggingface_vit():
+    """forward AND every parameter gradient of the oracle ('token' pooling) against transformers' ViT with the same weights"""
+    pytest.importorskip("transformers")
+    from transformers import ViTConfig, ViTModel
+    ref = _perturbed("vit_tiny_patch16_224", "token", 1)
+    hf = ViTModel(_hf_config(ViTConfig), add_pooling_layer=False).train()
+    back = _copy_into_hf(hf, ref)
+    x, y = tiny_batch()
+    ref.train()
+    feats = hf(pixel_values=x).last_hidden_state[:, 0]
+    want = F.linear(feats, ref.head.weight, ref.head.bias)           # the classifier is ours on both sides: its gradient ...
+    got = ref(x)
     assert rel_l2(got, want) < 5e-6
+    g_head = torch.autograd.grad(F.cross_entropy(want, y, label_smoothing=0.1), [ref.head.weight, ref.head.bias], retain_graph=True)
+    F.cross_entropy(want, y, label_smoothing=0.1).backward()
+    ref.zero_grad()
+    R.label_smoothing_ce(got, y, 0.1).backward()
+    assert rel_l2(ref.head.weight.grad, g_head[0]) < 5e-5 and rel_l2(ref.head.bias.grad, g_head[1]) < 5e-5   # ... is compared too
+    worst = _check_grads_against_hf(ref, hf, back, skip=("head.weight", "head.bias"))
+    print(f"oracle vs Hugging Face ViT: logits {rel_l2(got, want):.1e}, worst parameter gradient {worst:.1e}")
+
+
+def test_oracle_avg_pool_matches_huggingface_composition():
+    """global_pool='avg' (no final norm on the tokens, mean over the patch tokens, fc_norm, head: vision_transformer.py:529,603,616,
+    953-990) against transformers' encoder stack composed with stock functionals"""
+    pytest.importorskip("transformers")
+    from transformers import ViTConfig, ViTModel
+    ref = _perturbed("vit_tiny_patch16_224", "avg", 2)
+    hf = ViTModel(_hf_config(ViTConfig), add_pooling_layer=False).train()
+    back = _copy_into_hf(hf, ref)
+    x, y = tiny_batch()
+    ref.train()
+    last = hf(pixel_values=x, output_hidden_states=True).hidden_states[-1]        # the last block's output, before HF's final LayerNorm
+    pooled = F.layer_norm(last[:, 1:].mean(1), (192,), ref.fc_norm.weight, ref.fc_norm.bias, 1e-6)
+    want = F.linear(pooled, ref.head.weight, ref.head.bias)
+    got = ref(x)
+    assert rel_l2(got, want) < 5e-6
+    tail = [ref.fc_norm.weight, ref.fc_norm.bias, ref.head.weight, ref.head.bias]
+    g_tail = torch.autograd.grad(F.cross_entropy(want, y, label_smoothing=0.1), tail, retain_graph=True)
+    F.cross_entropy(want, y, label_smoothing=0.1).backward()
+    ref.zero_grad()
+    R.label_smoothing_ce(got, y, 0.1).backward()
+    for p, g in zip(tail, g_tail):
+        assert rel_l2(p.grad, g) < 5e-5
+    _check_grads_against_hf(ref, hf, back, skip=("fc_norm.weight", "fc_norm.bias", "head.weight", "head.bias"))
+
+
+def test_distilled_oracle_matches_huggingface_deit_with_teacher():
+    """the distilled variant (models/deit.py:28-119: dist_token after cls_token, 198 positions, two heads, their mean at inference,
+    both in distilled training) against transformers' DeiTForImageClassificationWithTeacher: logits of all three outputs and the
+    gradients of a loss on both heads"""
+    pytest.importorskip("transformers")
+    from transformers import DeiTConfig, DeiTForImageClassificationWithTeacher
+    ref = _perturbed("deit_tiny_distilled_patch16_224", "token", 3)
+    hf = DeiTForImageClassificationWithTeacher(_hf_config(DeiTConfig, num_labels=40)).train()
+    back = _copy_into_hf(hf, ref, prefix="deit.")
+    sd = hf.state_dict()
+    for k, v in (("cls_classifier.weight", ref.head.weight), ("cls_classifier.bias", ref.head.bias),
+                 ("distillation_classifier.weight", ref.head_dist.weight), ("distillation_classifier.bias", ref.head_dist.bias)):
+        assert sd[k].shape == v.shape
+        sd[k] = v.detach().clone()
+    hf.load_state_dict(sd)
+    back.update({"head.weight": ["cls_classifier.weight"], "head.bias": ["cls_classifier.bias"],
+                 "head_dist.weight": ["distillation_classifier.weight"], "head_dist.bias": ["distillation_classifier.bias"]})
+    x, y = tiny_batch()
+    ref.eval()
+    out = hf(pixel_values=x)
+    with torch.no_grad():
+        assert rel_l2(ref(x), out.logits) < 5e-6                      # inference: the mean of the two heads
+    ref.train(); ref.set_distilled_training(True)
+    a, b = ref(x)
+    assert rel_l2(a, out.cls_logits) < 5e-6 and rel_l2(b, out.distillation_logits) < 5e-6
+    ref.zero_grad()
+    (R.label_smoothing_ce(a, y, 0.1) + 0.5 * R.label_smoothing_ce(b, y.flip(0), 0.0)).backward()
+    (F.cross_entropy(out.cls_logits, y, label_smoothing=0.1) + 0.5 * F.cross_entropy(out.distillation_logits, y.flip(0))).backward()
+    worst = _check_grads_against_hf(ref, hf, back)
+    print(f"distilled oracle vs Hugging Face DeiT: worst parameter gradient {worst:.1e}")
+    ref.set_distilled_training(False)                                # training without the distillation flag: still the mean
+    assert rel_l2(ref(x), out.logits) < 5e-6
 
 
 def test_attention_explicit_backward_matches_autograd():
@@ -207,6 +311,26 @@ def test_golden_step_fixture():
         for n in ("head.bias", "fc_norm.weight", "blocks.1.attn.proj.bias"):
             assert rel_l2(dict(m.named_parameters())[n].grad, torch.from_numpy(gold["grad:" + n + tag])) < (1e-4 if not emu else 2e-2)
     assert list(gold["param_names"]) == [n for n, _ in tiny_model().named_parameters()]
+
+
+def test_golden_three_step_fixture():
+    """the loop restatement reproduces the committed 3-step run (regression guard for oracle/ref_engine.py + ref_vit.py)"""
+    from oracle.make_golden import TRAIN3_SEEDS, train3_schedules
+    gold = np.load(GOLD / "vit_tiny_d2_train3.npz")
+    torch.set_num_threads(1)
+    data = [tiny_batch(seed=s) for s in TRAIN3_SEEDS]
+    lr_sched, wd_sched = train3_schedules()
+    assert np.array_equal(gold["lr_schedule"], lr_sched) and np.array_equal(gold["wd_schedule"], wd_sched)
+    m = tiny_model()
+    groups = R.parameter_groups(m, 0.05, m.no_weight_decay())
+    assert [list(gold[f"group{i}_names"]) for i in range(2)] == [g["names"] for g in groups]
+    assert list(gold["group_weight_decay"]) == [g["weight_decay"] for g in groups]
+    losses = []
+    stats = ref_engine.ref_train_one_epoch(m, lambda o, t: R.label_smoothing_ce(o, t, 0.1), data, ref_engine.make_optimizer(m, 1e-3, 0.05), 0,
+                                           lr_sched, wd_sched, 3, 1, record=lambda i, o, l, mod: losses.append(l))
+    assert np.allclose(losses, gold["losses"], rtol=1e-5)
+    assert np.allclose([stats["loss"], stats["lr"], stats["class_acc"]], gold["stats"], rtol=1e-5)
+    assert np.allclose([p.detach().norm().item() for p in m.parameters()], gold["weight_norms_end"], rtol=1e-5)
 
 
 def test_golden_schedules_and_ops():
