@@ -46,8 +46,30 @@ def layernorm(x, w, b, eps=1e-6):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
-def gelu(x):
-    return F.gelu(x)   # exact erf form, nn.GELU() default
+def dgelu(x):
+    """d/dx of the exact (erf) GELU: Phi(x) + x * pdf(x)"""
+    return 0.5 * (1.0 + torch.erf(x * (0.5 ** 0.5))) + x * torch.exp(-0.5 * x * x) * (1.0 / math.sqrt(2.0 * math.pi))
+
+
+class _GeluKeptDerivative(torch.autograd.Function):
+    """exact GELU whose backward multiplies by the derivative as the HIP path keeps it between the passes: evaluated at the
+    (already bf16-rounded) pre-activation in fp32, then rounded to bf16 - one more bf16 storage point, like every other saved
+    activation"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(rb(dgelu(x)))
+        return F.gelu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return g * d
+
+
+def gelu(x, emulate=False):
+    """exact erf form, nn.GELU() default (timm Mlp act_layer); emulate=True: see _GeluKeptDerivative"""
+    return _GeluKeptDerivative.apply(x) if emulate else F.gelu(x)
 
 
 def im2col_patches(img: torch.Tensor, p: int) -> torch.Tensor:

@@ -151,7 +151,7 @@ class RefViT(nn.Module):
         tap('y2', y)
         f1 = act(y @ w(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias)
         tap('h', f1)
-        a = R.rnd(R.gelu(f1), E, fwd=True, bwd=False)
+        a = R.rnd(R.gelu(f1, emulate=E), E, fwd=True, bwd=False)
         tap('a', a)
         br = R.rnd(a @ w(blk.mlp.fc2.weight).t() + blk.mlp.fc2.bias, E, fwd=False, bwd=True)
         if s2 is not None:

@@ -20,14 +20,15 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
     a = rnd(M, K)
-    for n in (768, 1536, 2304, 3072):
+    for n in ((3072,) if len(sys.argv) > 3 else (768, 1536, 2304, 3072)):
         b = rnd(n, K)
         bias = torch.randn(n, device=dev)
         out = torch.empty((M, n), dtype=torch.bfloat16, device=dev)
         out2 = torch.empty((M, n), dtype=torch.bfloat16, device=dev)
         res = rnd(M, n)
         for name, epi, kw in (("plain", _lib.EPI_PLAIN, {}), ("bias", _lib.EPI_BIAS, {}), ("bias+res", _lib.EPI_BIAS_RES, dict(res=res)),
-                              ("bias+gelu", _lib.EPI_BIAS_GELU, dict(out2=out2)), ("dgelu", _lib.EPI_DGELU, dict(aux=res))):
+                              ("bias+gelu", _lib.EPI_BIAS_GELU, dict(out2=out2)), ("dgelu", _lib.EPI_DGELU, dict(aux=res)),
+                              ("bias+gelu+dg", _lib.EPI_BIAS_GELU_DG, dict(out2=out2)), ("mul", _lib.EPI_MUL, dict(aux=res))):
             ms = timeit(lambda: ops.gemm_nt(a, b, epilogue=epi, bias=bias, out=out, **kw), reps)
             tiles = ((M + 255) // 256) * ((n + 255) // 256)
             rounds = -(-tiles // 256)

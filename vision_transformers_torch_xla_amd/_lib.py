@@ -77,7 +77,7 @@ SIGNATURES = {
     "vitk_sumsq_workspace": (_sz, [_i64]),
 }
 
-EPI_PLAIN, EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_PATCH, EPI_DGELU = range(7)
+EPI_PLAIN, EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_PATCH, EPI_DGELU, EPI_BIAS_GELU_DG, EPI_MUL = range(9)
 
 
 class VitkError(RuntimeError):

@@ -115,6 +115,23 @@ static __device__ __forceinline__ void dgelu_erf2(float x0, float x1, float& y0,
     y0 = y[0]; y1 = y[1];
 }
 
+// gelu(x) and gelu'(x) of two elements at once: they share u, the erfc polynomial and its exponential; the derivative adds the
+// Gaussian's exponential
+static __device__ __forceinline__ void gelu_dgelu_erf2(float x0, float x1, float& y0, float& y1, float& g0, float& g1) {
+    const f32x2_t u = {fminf(fabsf(x0), 8.0f), fminf(fabsf(x1), 8.0f)};
+    const f32x2_t h = half_erfc_poly2(u);
+    const f32x2_t mx = {fmaxf(x0, 0.0f), fmaxf(x1, 0.0f)};
+    const f32x2_t y = __builtin_elementwise_fma(-u, h, mx);
+    const f32x2_t k = {-0.72134752044448170368f, -0.72134752044448170368f};
+    const f32x2_t e = (k * u) * u;
+    const f32x2_t x = {x0, x1};
+    const f32x2_t xs = x * (f32x2_t){0.39894228040143267794f, 0.39894228040143267794f};
+    const f32x2_t pdf = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    const f32x2_t cdf = {0.5f + copysignf(0.5f - h[0], x0), 0.5f + copysignf(0.5f - h[1], x1)};
+    const f32x2_t g = __builtin_elementwise_fma(xs, pdf, cdf);
+    y0 = y[0]; y1 = y[1]; g0 = g[0]; g1 = g[1];
+}
+
 // load 8 bf16 (16 B) as floats
 static __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
     const uint4 r = *reinterpret_cast<const uint4*>(p);

@@ -89,7 +89,7 @@ static __device__ __forceinline__ void add_f32(const float* q, float (&v)[W]) {
 // side operand of an epilogue (residual for BIAS_RES, pre-activation for DGELU): W bf16 of row m starting at column n
 template <int EPI>
 static __device__ __forceinline__ const bf16_t* nt_side_ptr(const GemmNTParams& p, int m, int n) {
-    return EPI == VITK_EPI_BIAS_RES ? p.res + (size_t)m * p.ldres + n : p.aux + (size_t)m * p.ldaux + n;
+    return EPI == VITK_EPI_BIAS_RES ? p.res + (size_t)m * p.ldres + n : p.aux + (size_t)m * p.ldaux + n;      // DGELU, MUL: aux
 }
 static __device__ __forceinline__ void unpack_bf16x8(const u32x4 r, float (&v)[8]) {
     v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
@@ -102,7 +102,7 @@ template <int EPI, int W>
 static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float (&v)[W], int m, int n, int orow, float rs,
                                                    const float* posrow, const float* side = nullptr,
                                                    const float* bias_regs = nullptr) {
-    if (EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU) {
+    if (EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU && EPI != VITK_EPI_MUL) {
         if (bias_regs) {
 #pragma unroll
             for (int j = 0; j < W; ++j) v[j] += bias_regs[j];
@@ -134,6 +134,32 @@ static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float 
             __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(cp));
         }
         store_bf16<W>(p.out2 + (size_t)m * p.ldout2 + n, a);
+    } else if (EPI == VITK_EPI_BIAS_GELU_DG) {
+        // as BIAS_GELU, but what is kept for the backward pass is gelu'(h), rounded to bf16, in place of h
+        unsigned gp[W / 2];
+        float a[W];
+#pragma unroll
+        for (int j = 0; j < W; j += 2) {
+            const unsigned hp = pack2bf(v[j], v[j + 1]);
+            float g0, g1;
+            gelu_dgelu_erf2(__uint_as_float(hp << 16), __uint_as_float(hp & 0xffff0000u), a[j], a[j + 1], g0, g1);
+            gp[j / 2] = pack2bf(g0, g1);
+        }
+        bf16_t* cp = (bf16_t*)p.C + (size_t)m * p.ldc + n;
+        if (W == 4) {
+            uint2 r; r.x = gp[0]; r.y = gp[1];
+            *reinterpret_cast<uint2*>(cp) = r;
+        } else {
+            const u32x4 r = {gp[0], gp[1], gp[W / 2 - 2], gp[W / 2 - 1]};
+            __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(cp));
+        }
+        store_bf16<W>(p.out2 + (size_t)m * p.ldout2 + n, a);
+    } else if (EPI == VITK_EPI_MUL) {
+        float h[W];
+        if (side == nullptr) load_bf16<W>(p.aux + (size_t)m * p.ldaux + n, h);
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[j] *= side ? side[j] : h[j];
+        store_bf16<W>((bf16_t*)p.C + (size_t)m * p.ldc + n, v);
     } else if (EPI == VITK_EPI_BIAS_RES) {
         float r[W];
         if (side == nullptr) load_bf16<W>(p.res + (size_t)orow * p.ldres + n, r);
@@ -450,7 +476,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         // 16-byte chunk c of staging row r sits at chunk c ^ (r & 7): conflict-free both ways.
         // The side operand (residual / pre-activation) may be the output buffer itself, so hipcc keeps every load behind
         // the previous store: fetch it by hand, 8 pieces (64 rows) ahead, to keep HBM latency out of the store loop.
-        constexpr bool SIDE = EPI == VITK_EPI_BIAS_RES || EPI == VITK_EPI_DGELU;
+        constexpr bool SIDE = EPI == VITK_EPI_BIAS_RES || EPI == VITK_EPI_DGELU || EPI == VITK_EPI_MUL;
         const int ecol = n0 + wn * 64 + (lane & 7) * 8;
         u32x4 side[SIDE ? 8 : 1];
         auto fetch_side = [&](int tm_base) {
@@ -465,7 +491,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         };
         if (SIDE) fetch_side(0);
         // the bias depends on the lane's columns only: one fetch per tile (behind the stores hipcc would re-load it 16 times)
-        constexpr bool BIAS = EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU;
+        constexpr bool BIAS = EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU && EPI != VITK_EPI_MUL;
         float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (BIAS) add_f32<8>(p.bias + (ecol < p.N ? ecol : 0), bias8);
 #pragma unroll
@@ -972,16 +998,16 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
                  "gemm_nt: K, lda, ldb must be multiples of 8 and lda,ldb >= K (K=%d lda=%d ldb=%d)", K, lda, ldb);
     VITK_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && ldc >= N, "gemm_nt: N and ldc must be multiples of 4, ldc >= N (N=%d ldc=%d)", N, ldc);
     VITK_REQUIRE(vitk_aligned(A, 16) && vitk_aligned(B, 16) && vitk_aligned(C, 16), "gemm_nt: operands must be 16-byte aligned");
-    VITK_REQUIRE(epilogue >= VITK_EPI_PLAIN && epilogue <= VITK_EPI_DGELU, "gemm_nt: unknown epilogue %d", epilogue);
-    if (epilogue != VITK_EPI_PLAIN && epilogue != VITK_EPI_DGELU)
+    VITK_REQUIRE(epilogue >= VITK_EPI_PLAIN && epilogue <= VITK_EPI_MUL, "gemm_nt: unknown epilogue %d", epilogue);
+    if (epilogue != VITK_EPI_PLAIN && epilogue != VITK_EPI_DGELU && epilogue != VITK_EPI_MUL)
         VITK_REQUIRE(bias && vitk_aligned(bias, 16), "gemm_nt: epilogue %d needs a 16-byte aligned bias", epilogue);
-    if (epilogue == VITK_EPI_BIAS_GELU)
+    if (epilogue == VITK_EPI_BIAS_GELU || epilogue == VITK_EPI_BIAS_GELU_DG)
         VITK_REQUIRE(out2 && ldout2 % 4 == 0 && ldout2 >= N && vitk_aligned(out2, 16), "gemm_nt: BIAS_GELU needs out2 (ld%%4==0)");
     if (epilogue == VITK_EPI_BIAS_RES) {
         VITK_REQUIRE(res && ldres % 4 == 0 && ldres >= N && vitk_aligned(res, 16), "gemm_nt: BIAS_RES needs res (ld%%4==0)");
         VITK_REQUIRE(!rowscale || rows_per_group > 0, "gemm_nt: rowscale needs rows_per_group > 0");
     }
-    if (epilogue == VITK_EPI_DGELU)
+    if (epilogue == VITK_EPI_DGELU || epilogue == VITK_EPI_MUL)
         VITK_REQUIRE(aux && ldaux % 4 == 0 && ldaux >= N && vitk_aligned(aux, 16), "gemm_nt: DGELU needs aux (ld%%4==0)");
     if (epilogue == VITK_EPI_PATCH)
         VITK_REQUIRE(pos && patches > 0 && prefix >= 0 && M % patches == 0 && vitk_aligned(pos, 16),
@@ -1021,6 +1047,8 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             VITK_LAUNCH_BIG(VITK_EPI_BIAS_RES)
             VITK_LAUNCH_BIG(VITK_EPI_PATCH)
             VITK_LAUNCH_BIG(VITK_EPI_DGELU)
+            VITK_LAUNCH_BIG(VITK_EPI_BIAS_GELU_DG)
+            VITK_LAUNCH_BIG(VITK_EPI_MUL)
         }
 #undef VITK_LAUNCH_BIG
     } else {
@@ -1034,6 +1062,8 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
             case VITK_EPI_BIAS_RES: gemm_nt_kernel<VITK_EPI_BIAS_RES><<<p.num_tiles, 256, 0, s>>>(p); break;
             case VITK_EPI_PATCH: gemm_nt_kernel<VITK_EPI_PATCH><<<p.num_tiles, 256, 0, s>>>(p); break;
             case VITK_EPI_DGELU: gemm_nt_kernel<VITK_EPI_DGELU><<<p.num_tiles, 256, 0, s>>>(p); break;
+            case VITK_EPI_BIAS_GELU_DG: gemm_nt_kernel<VITK_EPI_BIAS_GELU_DG><<<p.num_tiles, 256, 0, s>>>(p); break;
+            case VITK_EPI_MUL: gemm_nt_kernel<VITK_EPI_MUL><<<p.num_tiles, 256, 0, s>>>(p); break;
         }
     }
     if (pr) vitk_prof_end(stream);

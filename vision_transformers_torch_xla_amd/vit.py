@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import (EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_PATCH, EPI_PLAIN, VitkError)
+from ._lib import (EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_GELU_DG, EPI_BIAS_RES, EPI_MUL, EPI_PATCH, EPI_PLAIN, VitkError)
 
 bf16, f32 = torch.bfloat16, torch.float32
 _ALIGN = 64   # flat-buffer offsets are multiples of 64 elements (256 B fp32 / 128 B bf16)
@@ -540,8 +540,11 @@ class VisionTransformer(nn.Module):
                 c2 = s2 is not None and s2.compact
                 y2, m2, r2 = ops.layernorm_fwd(x2, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, smap=s2.kept if c2 else None,
                                                rows_per_sample=N)
+                # fc1's epilogue writes the activation a = gelu(h) and, for the backward pass, gelu'(h) in bf16 (named h below: it
+                # takes the pre-activation's place; multiplying by a stored derivative costs the backward GEMM's epilogue a third
+                # of what evaluating two exponentials per element there does)
                 a = torch.empty((y2.shape[0], blk.mlp.fc1.out_features), dtype=bf16, device=img.device)
-                h = ops.gemm_nt(y2, wb[pre + "mlp.fc1.weight"], epilogue=EPI_BIAS_GELU, bias=blk.mlp.fc1.bias, out2=a)
+                h = ops.gemm_nt(y2, wb[pre + "mlp.fc1.weight"], epilogue=EPI_BIAS_GELU_DG, bias=blk.mlp.fc1.bias, out2=a)
                 if c2:
                     x3 = torch.empty_like(x2)
                     ops.gemm_nt(a, wb[pre + "mlp.fc2.weight"], epilogue=EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x2, rowscale=s2.scale_c,
@@ -739,7 +742,7 @@ class VisionTransformer(nn.Module):
             else:
                 dout = branch_input_grad(dx, s2, dout_next)
                 wgrad(dout, a, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias")
-                dh = ops.gemm_nt(dout, wt[pre + "mlp.fc2.weight"], epilogue=EPI_DGELU, aux=h)
+                dh = ops.gemm_nt(dout, wt[pre + "mlp.fc2.weight"], epilogue=EPI_MUL, aux=h)
                 wgrad(dh, y2, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
                 dy2 = ops.gemm_nt(dh, wt[pre + "mlp.fc1.weight"])
                 del dh
