@@ -31,7 +31,7 @@ except ValueError:
 import torch
 import torch.distributed as dist
 
-PMC_HBM_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_hbm.json")
+PMC_HBM_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "pmc_hbm.json")
 PEAK_BF16_TFLOPS = 2500.0                                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                                        # HBM3E spec (6.3 TB/s measured achievable, same guide)
 
@@ -266,7 +266,7 @@ def main():
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 # HBM-side bytes per launch (average over this kernel family's launches of a step), from two separate
                 # rocprofv3 --pmc passes over this same command (FETCH_SIZE doubled as gfx950 needs, + WRITE_SIZE), written
-                # to profiles/pmc_hbm.json by tools/pmc_hbm.sh + tools/summarize_pmc_hbm.py.  Counters cannot be read from
+                # to tools/pmc_hbm.json by tools/pmc_hbm.sh + tools/summarize_pmc_hbm.py.  Counters cannot be read from
                 # inside the process, so this is the committed measurement for the default workload, null for any other.
                 **pmc_traffic(args),
                 "kernel": "gemm_ntp_kernel / gemm_nt_kernel (bf16 MFMA 16x16x32; all epilogue instantiations: forward linears + data gradients)",
