@@ -206,3 +206,44 @@ def test_training_steps_full_size_are_reproducible(device, cfg):
     assert 6.0 < l1[0].item() < 8.0                       # ln(1000) = 6.9 at initialisation
     assert torch.equal(l1, l2)
     assert torch.equal(p1, p2)
+
+
+def test_kd_workload_full_size_is_reproducible(device):
+    """Knowledge distillation at its benchmark size - DeiT-B/16 distilled student, ViT-B/16 teacher, 512 images, through
+    StudentWithDistillation + DistillationLoss(LabelSmoothingCE(0.1), alpha 0.7, T 4) and train_one_epoch for two steps:
+    the same bits twice, a loss of the size the formula gives at initialisation, a teacher that does not change."""
+    from vision_transformers_torch_xla_amd import engine, optim_factory
+    from vision_transformers_torch_xla_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy, StudentWithDistillation
+    from vision_transformers_torch_xla_amd.vit import create_model
+
+    Bk = 512
+    g = torch.Generator(device=device).manual_seed(0)
+    x = torch.randn(Bk, 3, 224, 224, generator=g, device=device)
+    t = torch.randint(0, 1000, (Bk,), generator=g, device=device)
+
+    def run():
+        torch.manual_seed(0)
+        student = create_model("deit_base_distilled_patch16_224", pretrained=False, num_classes=1000, drop_path_rate=0.1).to(device)
+        teacher = create_model("vit_base_patch16_224", pretrained=False, num_classes=1000, global_pool="avg", drop_path_rate=0.0).to(device)
+        teacher.eval()
+        for p in teacher.parameters():
+            p.requires_grad = False
+        t0 = teacher._flat["p"].clone()
+
+        class A:
+            opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 1e-3, 0.05, 1e-8, None
+        opt = optim_factory.create_optimizer(A, student)
+        model = StudentWithDistillation(student, teacher)
+        stats = engine.train_one_epoch(model, DistillationLoss(LabelSmoothingCrossEntropy(0.1), 0.7, 4.0), [(x, t), (x, t)], opt, device, 0,
+                                       None, 0, None, None, num_training_steps_per_epoch=2, update_freq=1, log_freq=1)
+        assert torch.equal(teacher._flat["p"], t0)
+        flat = student._flat["p"].clone()
+        del model, student, teacher, opt
+        return stats, flat
+
+    s1, p1 = run()
+    s2, p2 = run()
+    assert set(s1) == {"loss", "lr", "class_acc"} and torch.isfinite(p1).all()
+    # at initialisation both models are near-uniform over 1000 classes: CE ~ ln(1000) = 6.9, KL ~ 0 -> loss ~ 0.3 * 6.9
+    assert 1.8 < s1["loss"] < 2.6, s1
+    assert s1 == s2 and torch.equal(p1, p2)

@@ -1,16 +1,21 @@
-// bf16 MFMA GEMMs (fp32 accumulate) for the ViT linears, gfx950.
+// bf16 MFMA GEMMs (fp32 accumulate, v_mfma_f32_16x16x32_bf16) for the ViT linears, gfx950.
 //
-//   gemm_nt : C[M,N] = A[M,K] * B[N,K]^T   (forward linears, data gradients with a transposed weight copy)
-//   gemm_tn : C[N,K] = A[M,N]^T * B[M,K]   (weight gradients: contraction over the M token rows, split over M)
+//   gemm_nt : C[M,N] = A[M,K] * B[N,K]^T + fused epilogue   (forward linears; data gradients with a transposed weight copy)
+//   gemm_tn : C[N,K] = A[M,N]^T * B[M,K]                    (weight gradients: contraction over the M token rows)
 //
-// Both use v_mfma_f32_16x16x32_bf16 on a 128x128 block tile, 4 waves (2x2), each wave a 64x64 sub-tile
-// (4x4 MFMA tiles, 64 accumulator registers).  Operands are staged global -> registers -> LDS; the next
-// K-step's global loads are issued before the MFMAs of the current one.
-//   gemm_nt keeps K contiguous in LDS ([row][64] with a 16-byte-chunk XOR swizzle, conflict-free
-//   ds_read_b128 fragments).  gemm_tn keeps the output dimension contiguous ([m][128]) and builds the
-//   fragments with the transposing read ds_read_b64_tr_b16.
-// The MFMA operands are swapped (first operand = the matrix whose rows become output columns) so that each
-// lane ends up holding 4 consecutive output columns of one row: 8-byte (bf16) / 16-byte (fp32) stores.
+// Each has two kernels.
+//   gemm_ntp_kernel / gemm_tnb_kernel: the large-tile kernels every big linear takes - one 512-thread workgroup per compute
+//     unit, 256 x 256 tiles, 8 waves of 128 x 64 (128 accumulator registers), operands global -> LDS by LDS-DMA into a
+//     double-buffered 128 KB image, fragments read one 16-MFMA phase ahead.  gemm_ntp is persistent (a workgroup walks its
+//     tiles, the K-steps of all of them one continuous request stream) and transposes its accumulators through LDS so that
+//     every global access of the epilogue is a full line; gemm_tnb runs one (tile, row range) task per workgroup and leaves
+//     fp32 partial tiles for a fixed-order reduction.  Details at each kernel.
+//   gemm_nt_kernel / gemm_tn_kernel: 128 x 128 tiles, 4 waves, operands staged through registers; they take what the large
+//     kernels do not (K tails with zero fill, small M / N / K: the heads, unit tests).
+// gemm_nt keeps K contiguous in LDS ([row][64], 16-byte chunks XOR-swizzled: conflict-free ds_read_b128 fragments); gemm_tn
+// keeps the output dimension contiguous and builds its fragments with the transposing read ds_read_b64_tr_b16.
+// The MFMA operands are swapped (first operand = the matrix whose rows become output columns) so that a lane ends up holding
+// 4 consecutive output columns of one row.
 #include "common.h"
 #include <cstdlib>
 
@@ -1025,18 +1030,21 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     static const bool force_small = getenv("VITK_GEMM_SMALL") != nullptr;
     const bool ld8 = ldc % 8 == 0 && (!res || ldres % 8 == 0) && (!out2 || ldout2 % 8 == 0) && (!aux || ldaux % 8 == 0);   // 16-byte row pieces
     const bool big = !force_small && K % GBK == 0 && K >= 2 * GBK && M >= 512 && N >= 128 && N % 8 == 0 && ld8;
-    const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_NT);
+    const int cus = big ? vitk_num_cus() : 1;
+    if (cus <= 0) { vitk_set_error("gemm_nt: cannot query the compute-unit count"); return VITK_ELAUNCH; }
+    const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_NT);       // every return below closes the bracket
     if (big) {
         p.tiles_n = (N + LBN - 1) / LBN;
         p.num_tiles = ((M + LBM - 1) / LBM) * p.tiles_n;
         const size_t smem = NTP_LDS;
-        const int cus = vitk_num_cus();
-        if (cus <= 0) { vitk_set_error("gemm_nt: cannot query the compute-unit count"); return VITK_ELAUNCH; }
         const int grid = p.num_tiles < cus ? p.num_tiles : cus;      // one persistent workgroup per CU
 #define VITK_LAUNCH_BIG(E)                                                                                              \
     case E: {                                                                                                           \
         static VitkLdsOnce once = {};                                                                                   \
-        if (int rc_ = vitk_lds_once(once, (const void*)gemm_ntp_kernel<E>, smem, "gemm_nt")) return rc_;                \
+        if (int rc_ = vitk_lds_once(once, (const void*)gemm_ntp_kernel<E>, smem, "gemm_nt")) {                          \
+            if (pr) vitk_prof_end(stream);                                                                              \
+            return rc_;                                                                                                 \
+        }                                                                                                               \
         gemm_ntp_kernel<E><<<grid, 512, smem, s>>>(p);                                                         \
     } break;
         switch (epilogue) {
