@@ -171,6 +171,39 @@ def test_parameter_groups_and_optimizer_plan():
         optim_factory.create_optimizer(Bad, m)
 
 
+def test_optimizer_replan_keeps_moments_and_checks_shapes():
+    """A re-flattened model (.to(), .cuda(), a loaded state) makes the optimizer rebuild its flat moment buffers: what was
+    gathered so far must move into the new ones (the step count, hence the bias correction, carries on), and a state dict of
+    another parameter layout must be refused instead of being broadcast into the wrong moments."""
+    from vision_transformers_torch_xla_amd import optim_factory
+    from vision_transformers_torch_xla_amd._lib import VitkError
+    from vision_transformers_torch_xla_amd.vit import create_model
+    torch.manual_seed(0)
+    m = create_model("deit_tiny_distilled_patch16_224", num_classes=16, depth=1)
+
+    class Args:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 1e-3, 0.05, 1e-8, None
+    opt = optim_factory.create_optimizer(Args, m)
+    opt._build_plan()
+    opt._m.uniform_(-1, 1); opt._v.uniform_(0, 1); opt._steps = 5
+    before = {n: (opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for n, p in m.named_parameters()}
+    old_m = opt._m
+    m._flatten()                                           # what .to(device) does: new flat buffers, parameters re-pointed
+    assert opt._plan_stale()
+    opt._build_plan()
+    assert opt._m is not old_m and opt._steps == 5
+    for n, p in m.named_parameters():
+        assert torch.equal(opt.state[p]["exp_avg"], before[n][0]) and torch.equal(opt.state[p]["exp_avg_sq"], before[n][1]), n
+        assert float(opt.state[p]["step"]) == 5.0
+    # a state dict whose entries 1 and 2 are swapped (a model that registers dist_token before pos_embed): shapes do not fit
+    sd = opt.state_dict()
+    name_of = {id(q): n for n, q in m.named_parameters()}
+    idx = {name_of[id(p)]: k for g, sg in zip(opt.param_groups, sd["param_groups"]) for p, k in zip(g["params"], sg["params"])}
+    sd["state"][idx["pos_embed"]], sd["state"][idx["dist_token"]] = sd["state"][idx["dist_token"]], sd["state"][idx["pos_embed"]]
+    with pytest.raises(VitkError, match="does not fit"):
+        opt.load_state_dict(sd)
+
+
 def test_cosine_scheduler_matches_golden():
     from vision_transformers_torch_xla_amd import utils
     s = np.load(ROOT / "tests" / "golden" / "schedules.npz")

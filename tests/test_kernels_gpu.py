@@ -250,6 +250,28 @@ def test_attention_fwd_bwd(device, B, N, H):
     assert max(errs.values()) <= REL_TOL, errs
 
 
+def test_label_out_of_range_gives_nan_not_a_wild_read(device):
+    """a label outside [0, C) - an ignore_index of another code base, a head of another size - must not become an address: that
+    row's loss and gradient are NaN (the step fails loudly), every other row is untouched"""
+    from vision_transformers_torch_xla_amd.losses import CrossEntropyLoss, LabelSmoothingCrossEntropy
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(6, 40, generator=g)
+    good = torch.randint(0, 40, (6,), generator=g)
+    for bad_label in (-100, 40, 2 ** 40):
+        t = good.clone()
+        t[2] = bad_label
+        zg = z.clone().to(device).requires_grad_(True)
+        loss = LabelSmoothingCrossEntropy(0.1)(zg, t.to(device))
+        loss.backward()
+        assert torch.isnan(loss).item()
+        assert torch.isnan(zg.grad[2]).all() and torch.isfinite(zg.grad[[0, 1, 3, 4, 5]]).all()
+        zr = z.clone().requires_grad_(True)
+        keep = [0, 1, 3, 4, 5]
+        (F.cross_entropy(zr[keep], good[keep], label_smoothing=0.1, reduction="sum") / 6).backward()
+        assert rel_l2(zg.grad[keep], zr.grad[keep]) <= 1e-5
+    assert torch.isfinite(CrossEntropyLoss()(z.to(device), good.to(device))).item()
+
+
 def test_attention_matches_sdpa(device):
     """independent check of the kernel against torch's own scaled_dot_product_attention on CPU"""
     ops = _ops()
