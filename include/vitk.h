@@ -194,6 +194,31 @@ int vitk_preprocess_images(const void* src, int src_is_u8, const unsigned char* 
                            int src_h, int src_w, int top, int left, float vmin, float vmax, const float* mean3,
                            const float* std3, void* stream);
 
+/* ---- crop / resize stage of the input pipeline on the device: B decoded images of DIFFERENT sizes (uint8 HWC, 3 channels, packed
+ * one after the other in src; already on the device) become the fp32 NCHW batch dst [B, 3, S, S].  Per image a descriptor says
+ * which box of the source is resized to which size and which S x S window of the result is kept:
+ *   training   decode_jpeg_and_inception_crop(S) (big_vision/pp/ops_image.py:36-66): box = the sampled crop, out = S x S, win = (0, 0)
+ *   evaluation resize_small(R) | central_crop(S) (:85-134): box = the whole image, out = (new_h, new_w), win = the central offsets
+ *              (negative where the resized image is smaller than S: zero padding, as tf.image.resize_with_crop_or_pad)
+ * Arithmetic: u8 -> float32 * (1/255) (tf.image.convert_image_dtype), tf.image.resize(method, antialias=True) as the
+ * ScaleAndTranslate op computes it - rows first, then columns, float32, weights kernel(|src + 0.5 - sample| / kernel_scale)
+ * normalised per output index, kernel_scale = max(in / out, 1); kernel 0 = 'triangle' (BILINEAR), 1 = 'keyscubic' (BICUBIC) -
+ * then flip_lr (desc.flip), value_range, the layout change and the normalisation exactly as vitk_preprocess_images.
+ * The B descriptors are passed twice: desc_host (HOST memory) is validated before anything is launched - boxes inside their
+ * images, images inside the src_bytes of src, box width <= 12 288, at most 512 vertical filter taps (a 60-fold reduction with the
+ * cubic kernel) - and desc_dev is the same array on the device, read by the kernel.  S a multiple of 4, <= 1024. */
+typedef struct {
+    int64_t src_offset;            /* byte offset of the image's first pixel in src; rows are src_w * 3 bytes */
+    int32_t src_h, src_w;
+    int32_t box_y, box_x, box_h, box_w;
+    int32_t out_h, out_w;
+    int32_t win_y, win_x;
+    int32_t flip, reserved;
+} vitk_resample_desc;              /* 56 bytes */
+int vitk_resample_images(const unsigned char* src, int64_t src_bytes, const vitk_resample_desc* desc_host,
+                         const vitk_resample_desc* desc_dev, float* dst, int B, int S, int kernel, float vmin, float vmax,
+                         const float* mean3, const float* std3, void* stream);
+
 /* ---- mixup / cutmix in 'batch' mode on the device, in place on the fp32 NCHW batch x [B, per_sample]; sample b is paired
  * with sample B-1-b (x.flip(0)); B must be even.  Replaces timm.data.Mixup.__call__ as the reference applies it before
  * every training step (main.py:622-629, engine.py:132-133, 259-260).

@@ -1,0 +1,166 @@
+"""Crop / resize stage of the input pipeline on the device (vitk_resample_images, data.ResampleLoader) against the CPU oracle's
+restatement of tf.image.resize(antialias=True) (oracle/ref_resize.py), and the oracle itself against an independent
+implementation (torch's antialiased interpolation, the same triangle / Keys-cubic filters written by other people).
+Bit-exact where both sides run the same float32 operations in the same order; TensorFlow itself cannot run here, so parity
+with the reference's host stage is unpinned (see the oracle's header)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_preprocess as RP
+from oracle import ref_resize as RR
+
+
+def _img(h, w, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    # smooth content beside the noise, so that a wrong tap order or weight shows up as a pattern, not just as noise
+    yy, xx = np.mgrid[0:h, 0:w]
+    grad = ((yy * 255 // max(h - 1, 1)) ^ (xx * 255 // max(w - 1, 1))).astype(np.uint8)
+    return np.where(rng.random((h, w, 1)) < 0.5, base, grad[..., None].repeat(3, 2)).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------ oracle (CPU)
+@pytest.mark.parametrize("kernel,mode", [("triangle", "bilinear"), ("keyscubic", "bicubic")])
+@pytest.mark.parametrize("h,w,oh,ow", [(64, 48, 24, 24), (37, 91, 224, 224), (300, 200, 64, 80), (50, 50, 50, 50)])
+def test_oracle_resize_matches_torch_antialias(kernel, mode, h, w, oh, ow):
+    img = RR.to_float01(_img(h, w, h * 7 + w))
+    got = RR.resize_antialias(img, oh, ow, kernel)
+    want = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(oh, ow), mode=mode, antialias=True, align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(got - want).max() <= 2e-5, np.abs(got - want).max()
+    if (h, w) == (oh, ow):
+        assert np.array_equal(got, img)                    # same size: one tap of weight 1
+
+
+def test_oracle_spans_and_geometry():
+    # weights of every output index sum to 1 and stay inside the image; a constant image stays constant
+    for in_size, out_size in ((500, 224), (100, 224), (224, 224), (3, 7), (4000, 224)):
+        for k in ("triangle", "keyscubic"):
+            for s, w in RR.compute_spans(in_size, out_size, k):
+                assert 0 <= s and s + len(w) <= in_size and abs(float(w.sum()) - 1.0) <= 1e-5
+    const = np.full((40, 30, 3), 0.625, np.float32)
+    assert np.abs(RR.resize_antialias(const, 17, 23, "keyscubic") - 0.625).max() <= 1e-6
+    # resize_small / central crop: the shorter side becomes `size`; crop offsets as tf.image.resize_with_crop_or_pad
+    assert RR.resize_small_size(375, 500, 256) == (256, 341) and RR.resize_small_size(500, 375, 256) == (341, 256)
+    assert RR.resize_small_size(100, 80, 256) == (320, 256)
+    a = np.arange(10 * 12 * 3, dtype=np.float32).reshape(10, 12, 3)
+    assert np.array_equal(RR.crop_or_pad(a, 6), a[2:8, 3:9])
+    p = RR.crop_or_pad(a[:4, :5], 8)
+    assert np.array_equal(p[2:6, 1:6], a[:4, :5]) and p.sum() == a[:4, :5].sum()
+    # the sampled boxes respect the area and aspect bounds of decode_jpeg_and_inception_crop
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        h, w = (int(v) for v in rng.integers(16, 800, 2))
+        y, x, bh, bw = RR.sample_inception_box(h, w, rng)
+        assert 0 <= y and 0 <= x and y + bh <= h and x + bw <= w and bh > 0 and bw > 0
+        if (bh, bw) != (h, w):
+            assert 0.08 * h * w - 1e-9 <= bh * bw <= h * w and 0.70 <= bw / bh <= 1.40
+
+
+def test_host_geometry_matches_oracle():
+    from vision_transformers_torch_xla_amd import data
+    for seed in range(100):
+        h, w = (int(v) for v in np.random.default_rng(seed).integers(12, 900, 2))
+        assert data.sample_inception_box(h, w, np.random.default_rng(500 + seed)) == RR.sample_inception_box(h, w, np.random.default_rng(500 + seed))
+        assert data.resize_small_size(h, w, 256) == RR.resize_small_size(h, w, 256)
+    imgs = [_img(40, 60, 1), _img(300, 200, 2), _img(256, 256, 3)]
+    flat, offs = data.pack_images(imgs)
+    assert all(o % 16 == 0 for o in offs) and all(np.array_equal(flat[o:o + im.size].reshape(im.shape), im) for o, im in zip(offs, imgs))
+    d = data.eval_descriptors(imgs, offs, 64, 56)
+    for b, im in enumerate(imgs):
+        nh, nw = RR.resize_small_size(im.shape[0], im.shape[1], 64)
+        assert (d[b]["out_h"], d[b]["out_w"]) == (nh, nw) and (d[b]["win_y"], d[b]["win_x"]) == ((nh - 56) // 2, (nw - 56) // 2)
+    small = data.eval_descriptors([_img(10, 30, 4)], [0], 20, 56)       # 20 x 60 after the resize: padded rows, cropped columns
+    assert (small[0]["win_y"], small[0]["win_x"]) == (-18, 2)
+
+
+def test_resample_entry_point_validates_on_the_host():
+    """bad descriptors are refused before anything is launched (no GPU needed to see that)"""
+    from vision_transformers_torch_xla_amd import _lib, ops
+    lib = _lib.load()
+    d = np.zeros(1, dtype=ops.RESAMPLE_DESC)
+    d[0] = (0, 10, 10, 0, 0, 10, 10, 8, 8, 0, 0, 0, 0)
+    dummy = ctypes.create_string_buffer(4096)
+    addr = ctypes.addressof(dummy) // 16 * 16 + 16
+
+    def call(desc, src_bytes=300, size=8, kernel=0):
+        return lib.vitk_resample_images(addr, src_bytes, desc.ctypes.data, addr, addr, 1, size, kernel, 0.0, 1.0, None, None, None)
+    bad = d.copy(); bad[0]["box_w"] = 11
+    assert call(bad) != 0 and b"outside" in lib.vitk_last_error()
+    assert call(d, src_bytes=299) != 0 and b"does not fit" in lib.vitk_last_error()
+    assert call(d, size=6) != 0 and call(d, kernel=2) != 0
+    far = d.copy(); far[0]["src_h"] = far[0]["box_h"] = 6000; far[0]["out_h"] = 8
+    assert call(far, src_bytes=6000 * 10 * 3) != 0 and b"filter taps" in lib.vitk_last_error()
+
+
+# ------------------------------------------------------------------------------------------------- device (GPU)
+def _oracle_batch(images, desc, size, kernel, normalize=True):
+    out = []
+    for b, im in enumerate(images):
+        d = desc[b]
+        box = RR.to_float01(im)[d["box_y"]:d["box_y"] + d["box_h"], d["box_x"]:d["box_x"] + d["box_w"]]
+        r = RR.resize_antialias(box, int(d["out_h"]), int(d["out_w"]), kernel)
+        win = np.zeros((size, size, 3), np.float32)
+        y0, x0 = int(d["win_y"]), int(d["win_x"])
+        ys, xs = max(y0, 0), max(x0, 0)
+        ye, xe = min(y0 + size, r.shape[0]), min(x0 + size, r.shape[1])
+        win[ys - y0:ye - y0, xs - x0:xe - x0] = r[ys:ye, xs:xe]
+        out.append(RP.preprocess_image(win, bool(d["flip"]), 0.0, 1.0, "imagenet" if normalize else "none"))
+    return torch.stack(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["triangle", "keyscubic"])
+def test_resample_kernel_is_bit_exact_with_the_oracle(device, kernel):
+    from vision_transformers_torch_xla_amd import data, ops
+    from vision_transformers_torch_xla_amd.data import IMAGENET_DEFAULT_MEAN as M, IMAGENET_DEFAULT_STD as SD
+    images = [_img(h, w, 10 + i) for i, (h, w) in enumerate([(120, 160), (64, 48), (333, 500), (40, 40), (90, 17), (256, 300)])]
+    flat, offs = data.pack_images(images)
+    size = 56
+    boxes = [(10, 20, 100, 120), (0, 0, 64, 48), (33, 100, 280, 390), (5, 5, 30, 30), (0, 0, 90, 17), (100, 50, 57, 57)]   # down, same, up, 1:1
+    train = data.train_descriptors(images, offs, size, None, boxes=boxes, flips=[0, 1, 1, 0, 1, 0])
+    evald = data.eval_descriptors(images, offs, 64, size)
+    evald[4]["flip"] = 1                                                   # a padded, flipped image
+    src = torch.from_numpy(flat).to(device)
+    for desc in (train, evald):
+        got = ops.resample_images(src, desc, size, kernel=kernel, mean=M, std=SD)
+        want = _oracle_batch(images, desc, size, kernel)
+        assert got.shape == (len(images), 3, size, size)
+        diff = (got.cpu() - want).abs().max().item()
+        assert torch.equal(got.cpu(), want), diff
+    raw = ops.resample_images(src, train, size, kernel=kernel)           # no normalisation: values stay in [0, 1] (+ cubic overshoot)
+    assert torch.equal(raw.cpu(), _oracle_batch(images, train, size, kernel, normalize=False))
+
+
+@pytest.mark.gpu
+def test_resample_loader_over_an_image_folder(device, tmp_path):
+    """decode (PIL) -> pack -> GPU crop / resize / flip / normalise, for the training and the evaluation chain, against the oracle
+    composed from the same decoded pixels and the loader's own draws"""
+    from PIL import Image
+    from vision_transformers_torch_xla_amd import data
+    sizes = [(80, 120), (64, 64), (150, 100), (50, 210), (96, 96), (33, 47), (120, 90)]
+    for i, (h, w) in enumerate(sizes):
+        cls = tmp_path / f"class_{i % 3}"
+        cls.mkdir(exist_ok=True)
+        Image.fromarray(_img(h, w, 70 + i)).save(cls / f"im_{i}.png")
+    folder = data.DecodedImageFolder(str(tmp_path), batch_size=3, shuffle=True, seed=5, workers=2)
+    assert folder.classes == ["class_0", "class_1", "class_2"] and len(folder) == 2
+    for train in (True, False):
+        loader = data.ResampleLoader(folder, device, size=32, train=train, resize=40, seed=11)
+        loader.set_epoch(2)
+        seen = 0
+        ref_folder = data.DecodedImageFolder(str(tmp_path), batch_size=3, shuffle=True, seed=5, workers=1)
+        ref_folder.set_epoch(2)
+        rng = np.random.default_rng(11 + 3)                             # the loader's epoch counter after set_epoch(2) + iteration start
+        for (x, y), (imgs, labels) in zip(loader, ref_folder):
+            flat, offs = data.pack_images(imgs)
+            desc = data.train_descriptors(imgs, offs, 32, rng) if train else data.eval_descriptors(imgs, offs, 40, 32)
+            want = _oracle_batch(imgs, desc, 32, "triangle" if train else "keyscubic")
+            assert x.shape == (3, 3, 32, 32) and x.dtype == torch.float32 and x.device.type == "cuda"
+            assert torch.equal(x.cpu(), want)
+            assert torch.equal(y.cpu(), torch.from_numpy(labels))
+            seen += 1
+        assert seen == 2

@@ -88,7 +88,165 @@ __global__ __launch_bounds__(256) void images_to_nchw_kernel(const void* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Crop + antialiased resize of decoded images of different sizes (tf.image.resize(..., antialias=True) = ScaleAndTranslate).
+// One workgroup per (image, output row).  The row's vertical span and weights are computed once (LDS); every thread then forms
+// the vertically filtered source row for its columns of the box - the intermediate row of the two-pass algorithm, kept in LDS -
+// and after a barrier every thread filters it horizontally for its output pixels.  Sums start at zero and add weight * value in
+// ascending source order, multiply and add rounded separately, so the result is bit-identical to the two-pass float32 host code.
+static __device__ __forceinline__ float resample_kernel(int kind, float x) {
+#pragma clang fp contract(off)
+    x = fabsf(x);
+    if (kind == 0) return x < 1.0f ? 1.0f - x : 0.0f;
+    if (x >= 2.0f) return 0.0f;
+    if (x >= 1.0f) return ((-0.5f * x + 2.5f) * x - 4.0f) * x + 2.0f;
+    return ((1.5f * x - 2.5f) * x) * x + 1.0f;
+}
+// span of output index o: first source index, count, sampling position; in / out sizes as ints
+struct ResampleAxis { float inv_scale, kernel_scale, one_over, radius; int in_size; };
+static __device__ __forceinline__ ResampleAxis resample_axis(int in_size, int out_size, int kind) {
+#pragma clang fp contract(off)
+    ResampleAxis a;
+    const float scale = (float)out_size / (float)in_size;
+    a.inv_scale = (float)(1.0 / (double)scale);
+    a.kernel_scale = fmaxf(a.inv_scale, 1.0f);
+    a.one_over = 1.0f / a.kernel_scale;
+    a.radius = kind == 0 ? 1.0f : 2.0f;
+    a.in_size = in_size;
+    return a;
+}
+static __device__ __forceinline__ void resample_span(const ResampleAxis& a, int o, int& start, int& count, float& sample) {
+#pragma clang fp contract(off)
+    sample = ((float)o + 0.5f) * a.inv_scale;
+    const float reach = a.radius * a.kernel_scale;
+    int s = (int)ceilf((sample - reach) - 0.5f);
+    int e = (int)floorf((sample + reach) - 0.5f);
+    s = min(max(s, 0), a.in_size - 1);
+    e = min(max(e, 0), a.in_size - 1) + 1;
+    start = s;
+    count = e - s;
+}
+static __device__ __forceinline__ float resample_weight(const ResampleAxis& a, int kind, int src, float sample) {
+#pragma clang fp contract(off)
+    const float pos = ((float)src + 0.5f) - sample;
+    return resample_kernel(kind, pos * a.one_over);
+}
+
+#define RESAMPLE_MAX_TAPS 512      // vertical taps kept in LDS: covers a 60-fold reduction with the cubic kernel
+
+__global__ __launch_bounds__(256) void resample_kernel_rows(const unsigned char* __restrict__ src, const vitk_resample_desc* __restrict__ desc,
+                                                            float* __restrict__ dst, int S, int kind, float scale, float vmin, int normalise,
+                                                            float m0, float m1, float m2, float s0, float s1, float s2) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float rs_smem[];
+    float* wy = rs_smem;                               // [RESAMPLE_MAX_TAPS] normalised vertical weights of this output row
+    float* inter = rs_smem + RESAMPLE_MAX_TAPS;        // [box_w][3] vertically filtered row
+    const int b = blockIdx.x / S, y = blockIdx.x % S;
+    const vitk_resample_desc d = desc[b];
+    const size_t plane = (size_t)S * S;
+    float* out_row = dst + (size_t)b * 3 * plane + (size_t)y * S;
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    auto finish = [&](float t, int c) {                // value_range (float input) and normalisation, as vitk_preprocess_images
+        t = t * scale + vmin;
+        if (normalise) t = (t - mean[c]) / stdv[c];
+        return t;
+    };
+    const int oy = y + d.win_y;
+    if (oy < 0 || oy >= d.out_h) {                      // a padded row (the resized image is shorter than the window)
+        for (int x = threadIdx.x; x < S; x += blockDim.x)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out_row[c * plane + x] = finish(0.0f, c);
+        return;
+    }
+    const ResampleAxis ay = resample_axis(d.box_h, d.out_h, kind);
+    int ys, yn;
+    float ysample;
+    resample_span(ay, oy, ys, yn, ysample);
+    if (yn > RESAMPLE_MAX_TAPS) yn = RESAMPLE_MAX_TAPS;              // refused on the host; never taken
+    for (int i = threadIdx.x; i < yn; i += blockDim.x) wy[i] = resample_weight(ay, kind, ys + i, ysample);
+    __syncthreads();
+    float ytotal = 0.0f;
+    for (int i = 0; i < yn; ++i) ytotal += wy[i];
+    const bool ynorm = fabsf(ytotal) >= 1000.0f * 1.17549435e-38f;
+    const float yinv = 1.0f / ytotal;
+    // vertical pass: inter[col][c] = sum_i (wy[i] * yinv) * (u8 * (1/255))
+    const unsigned char* box = src + d.src_offset + ((size_t)(d.box_y + ys) * d.src_w + d.box_x) * 3;
+    const size_t row_bytes = (size_t)d.src_w * 3;
+    const float k255 = (float)(1.0 / 255.0);
+    for (int e = threadIdx.x; e < d.box_w * 3; e += blockDim.x) {
+        float acc = 0.0f;
+        const unsigned char* p = box + e;
+        for (int i = 0; i < yn; ++i) {
+            const float w = ynorm ? wy[i] * yinv : 0.0f;
+            const float v = (float)p[(size_t)i * row_bytes] * k255;
+            acc = acc + w * v;
+        }
+        inter[e] = acc;
+    }
+    __syncthreads();
+    // horizontal pass
+    const ResampleAxis ax = resample_axis(d.box_w, d.out_w, kind);
+    for (int x = threadIdx.x; x < S; x += blockDim.x) {
+        const int xo = (d.flip ? S - 1 - x : x) + d.win_x;      // flip_lr acts on the finished S x S image
+        float r[3] = {0.0f, 0.0f, 0.0f};
+        if (xo >= 0 && xo < d.out_w) {
+            int xs, xn;
+            float xsample;
+            resample_span(ax, xo, xs, xn, xsample);
+            float total = 0.0f;
+            for (int i = 0; i < xn; ++i) total += resample_weight(ax, kind, xs + i, xsample);
+            const bool norm = fabsf(total) >= 1000.0f * 1.17549435e-38f;
+            const float inv = 1.0f / total;
+            for (int i = 0; i < xn; ++i) {
+                const float w = norm ? resample_weight(ax, kind, xs + i, xsample) * inv : 0.0f;
+                const float* q = inter + (size_t)(xs + i) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) r[c] = r[c] + w * q[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out_row[c * plane + x] = finish(r[c], c);
+    }
+}
+
 extern "C" {
+
+int vitk_resample_images(const unsigned char* src, int64_t src_bytes, const vitk_resample_desc* desc_host,
+                         const vitk_resample_desc* desc_dev, float* dst, int B, int S, int kernel, float vmin, float vmax,
+                         const float* mean3, const float* std3, void* stream) {
+    VITK_REQUIRE(src && desc_host && desc_dev && dst && B > 0 && src_bytes > 0, "resample_images: bad arguments");
+    VITK_REQUIRE(S > 0 && S % 4 == 0 && S <= 1024, "resample_images: output size %d must be a multiple of 4, at most 1024", S);
+    VITK_REQUIRE(kernel == 0 || kernel == 1, "resample_images: kernel must be 0 (triangle / BILINEAR) or 1 (keyscubic / BICUBIC)");
+    VITK_REQUIRE((mean3 == nullptr) == (std3 == nullptr), "resample_images: mean and std go together");
+    VITK_REQUIRE(vitk_aligned(dst, 16) && vitk_aligned(desc_dev, 8), "resample_images: dst / desc alignment");
+    int max_box_w = 1;
+    for (int b = 0; b < B; ++b) {
+        const vitk_resample_desc& d = desc_host[b];
+        VITK_REQUIRE(d.src_h > 0 && d.src_w > 0 && d.src_offset >= 0 && d.src_offset + (int64_t)d.src_h * d.src_w * 3 <= src_bytes,
+                     "resample_images: image %d (%d x %d at byte %lld) does not fit the %lld source bytes", b, d.src_h, d.src_w,
+                     (long long)d.src_offset, (long long)src_bytes);
+        VITK_REQUIRE(d.box_h > 0 && d.box_w > 0 && d.box_y >= 0 && d.box_x >= 0 && d.box_y + d.box_h <= d.src_h && d.box_x + d.box_w <= d.src_w,
+                     "resample_images: image %d: box %d x %d at (%d, %d) outside the %d x %d image", b, d.box_h, d.box_w, d.box_y, d.box_x,
+                     d.src_h, d.src_w);
+        VITK_REQUIRE(d.out_h > 0 && d.out_w > 0 && d.box_w <= 12288, "resample_images: image %d: bad output size or a box wider than 12288", b);
+        // vertical taps of one output row: 2 * ceil(radius * max(in / out, 1)) + 1
+        const double ks = d.box_h > d.out_h ? (double)d.box_h / d.out_h : 1.0;
+        VITK_REQUIRE(2.0 * (kernel == 0 ? 1.0 : 2.0) * ks + 3.0 <= RESAMPLE_MAX_TAPS,
+                     "resample_images: image %d: a %d -> %d row reduction needs more than %d filter taps", b, d.box_h, d.out_h, RESAMPLE_MAX_TAPS);
+        if (d.box_w > max_box_w) max_box_w = d.box_w;
+    }
+    const int normalise = mean3 != nullptr;
+    const float m0 = normalise ? mean3[0] : 0.f, m1 = normalise ? mean3[1] : 0.f, m2 = normalise ? mean3[2] : 0.f;
+    const float s0 = normalise ? std3[0] : 1.f, s1 = normalise ? std3[1] : 1.f, s2 = normalise ? std3[2] : 1.f;
+    VITK_REQUIRE(s0 != 0.f && s1 != 0.f && s2 != 0.f, "resample_images: std must be non-zero");
+    const size_t smem = ((size_t)RESAMPLE_MAX_TAPS + (size_t)max_box_w * 3) * sizeof(float);
+    static VitkLdsOnce once = {};
+    if (int rc_ = vitk_lds_once(once, (const void*)resample_kernel_rows, ((size_t)RESAMPLE_MAX_TAPS + 12288 * 3) * sizeof(float), "resample_images"))
+        return rc_;
+    resample_kernel_rows<<<B * S, 256, smem, (hipStream_t)stream>>>(src, desc_dev, dst, S, kernel, vmax - vmin, vmin, normalise, m0, m1, m2, s0,
+                                                                    s1, s2);
+    return vitk_check_launch("resample_images");
+}
 
 int vitk_preprocess_images(const void* src, int src_is_u8, const unsigned char* flip, float* dst, int B, int H, int W, int src_h,
                            int src_w, int top, int left, float vmin, float vmax, const float* mean3, const float* std3,

@@ -6,6 +6,7 @@ device/dtype/contiguity, then hands raw device pointers, shapes and ``torch.cuda
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -485,4 +486,42 @@ def preprocess_images(src, flip=None, out=None, window=None, value_range=(0.0, 1
     check(_lib.load().vitk_preprocess_images(_ptr(src), int(src.dtype == torch.uint8), _ptr(flip), _ptr(out), B, int(H), int(W), Hs, Ws,
                                              int(top), int(left), float(value_range[0]), float(value_range[1]), m, s, _stream()),
           "preprocess_images")
+    return out
+
+
+RESAMPLE_DESC = np.dtype([("src_offset", "<i8"), ("src_h", "<i4"), ("src_w", "<i4"), ("box_y", "<i4"), ("box_x", "<i4"), ("box_h", "<i4"),
+                          ("box_w", "<i4"), ("out_h", "<i4"), ("out_w", "<i4"), ("win_y", "<i4"), ("win_x", "<i4"), ("flip", "<i4"),
+                          ("reserved", "<i4")])          # vitk_resample_desc (include/vitk.h), 56 bytes
+
+
+def resample_images(src, desc, size, kernel="triangle", out=None, value_range=(0.0, 1.0), mean=None, std=None, desc_dev=None):
+    """Decoded uint8 images of different sizes, packed one after the other in `src` (1-D uint8 on the GPU), -> fp32 NCHW
+    [B, 3, size, size]: per image the box desc['box_*'] is resized to desc['out_*'] with tf.image.resize(antialias=True)'s
+    arithmetic ('triangle' = BILINEAR, 'keyscubic' = BICUBIC) and the size x size window at desc['win_*'] of the result is
+    kept; then flip / value_range / normalisation as preprocess_images.  desc: numpy structured array of RESAMPLE_DESC (host);
+    desc_dev: the same bytes already on the GPU (uint8 tensor), copied here when not given."""
+    import ctypes
+    _chk(src, torch.uint8, "src")
+    desc = np.ascontiguousarray(desc, dtype=RESAMPLE_DESC)
+    B = int(desc.shape[0])
+    if kernel not in ("triangle", "keyscubic"):
+        raise _lib.VitkError(f"resample_images: kernel must be 'triangle' or 'keyscubic', got {kernel!r}")
+    if desc_dev is None:
+        desc_dev = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(src.device)
+    _chk(desc_dev, torch.uint8, "desc_dev")
+    if desc_dev.numel() != B * RESAMPLE_DESC.itemsize:
+        raise _lib.VitkError(f"desc_dev: expected {B * RESAMPLE_DESC.itemsize} bytes, got {desc_dev.numel()}")
+    if out is None:
+        out = torch.empty((B, 3, size, size), dtype=f32, device=src.device)
+    else:
+        _chk(out, f32, "out")
+        if tuple(out.shape) != (B, 3, size, size):
+            raise _lib.VitkError(f"out: expected {(B, 3, size, size)}, got {tuple(out.shape)}")
+    if (mean is None) != (std is None):
+        raise _lib.VitkError("mean and std go together")
+    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    s = (ctypes.c_float * 3)(*std) if std is not None else None
+    check(_lib.load().vitk_resample_images(_ptr(src), int(src.numel()), desc.ctypes.data, _ptr(desc_dev), _ptr(out), B, int(size),
+                                           0 if kernel == "triangle" else 1, float(value_range[0]), float(value_range[1]), m, s, _stream()),
+          "resample_images")
     return out
