@@ -164,3 +164,28 @@ def test_resample_loader_over_an_image_folder(device, tmp_path):
             assert torch.equal(y.cpu(), torch.from_numpy(labels))
             seen += 1
         assert seen == 2
+
+
+@pytest.mark.gpu
+def test_training_and_evaluation_through_the_loaders(device, tmp_path):
+    """an image folder -> ResampleLoader -> train_one_epoch / evaluate: the loaders hand the loops what they consume"""
+    from PIL import Image
+    from vision_transformers_torch_xla_amd import data, engine, optim_factory
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+    for i in range(12):
+        cls = tmp_path / f"c{i % 4}"
+        cls.mkdir(exist_ok=True)
+        Image.fromarray(_img(70 + 5 * i, 90 + 3 * i, 200 + i)).save(cls / f"{i}.jpg", quality=95)
+    torch.manual_seed(0)
+    model = create_model("vit_tiny_patch16_224", num_classes=8, global_pool="avg", depth=1, img_size=64).to(device)
+
+    class A:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 1e-3, 0.05, 1e-8, None
+    opt = optim_factory.create_optimizer(A, model)
+    train = data.ResampleLoader(data.DecodedImageFolder(str(tmp_path), 4, shuffle=True, seed=1, workers=2), device, size=64, train=True, seed=1)
+    stats = engine.train_one_epoch(model, LabelSmoothingCrossEntropy(0.1), train, opt, device, 0, None, 0, None, None, log_freq=1)
+    assert set(stats) == {"loss", "lr", "class_acc"} and np.isfinite(stats["loss"]) and 1.0 < stats["loss"] < 4.0
+    val = data.ResampleLoader(data.DecodedImageFolder(str(tmp_path), 6, drop_last=False, workers=2), device, size=64, train=False, resize=72)
+    ev = engine.evaluate(val, model, device)
+    assert set(ev) == {"loss", "acc1", "acc5"} and 0.0 <= ev["acc1"] <= ev["acc5"] <= 100.0
