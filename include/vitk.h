@@ -141,6 +141,12 @@ int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int
 size_t vitk_attention_bwd_workspace(int B, int N, int H);
 int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                        int B, int N, int H, float scale, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for head dims other than 64 - a multiple of 8 up to 96 (48 and 72: my_vit_mini / my_vit_xs, models/my_vit.py:84-165) -
+ * and up to 256 tokens: qkv [B*N, 3*H*head_dim], out / dout [B*N, H*head_dim], dqkv like qkv, lse [B, H, N].  Vector arithmetic
+ * (one thread per row) with the bf16 storage points of the 64-wide kernels; no workspace. */
+int vitk_attention_generic_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int head_dim, float scale, void* stream);
+int vitk_attention_generic_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N, int H,
+                               int head_dim, float scale, void* stream);
 
 /* ---- patch embedding front end / pooling tail.
  * im2col: NCHW fp32 image -> bf16 patch matrix [B*gh*gw, C*p*p], k = c*p*p + ky*p + kx, patch index gy*gw+gx

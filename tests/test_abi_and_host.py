@@ -82,8 +82,13 @@ def test_create_model_registry_and_errors():
         create_model("convnext_tiny")
     with pytest.raises(RuntimeError, match="pretrained"):
         create_model("vit_tiny_patch16_224", pretrained=True)
-    with pytest.raises(VitkError, match="head dim 64"):
-        create_model("my_vit_mini")
+    # every size of models/my_vit.py:84-165 builds: head dims 48 (mini) and 72 (xs) beside 64
+    assert [(create_model(n, depth=1).head_dim, create_model(n, depth=1).num_heads) for n in ("my_vit_mini", "my_vit_ti", "my_vit_xs", "my_vit_s")] == \
+        [(48, 3), (64, 3), (72, 4), (64, 6)]
+    with pytest.raises(VitkError, match="head dim"):
+        create_model("vit_tiny_patch16_224", embed_dim=200, num_heads=4, depth=1)               # 50: not a multiple of 8
+    with pytest.raises(VitkError, match="tokens exceed"):
+        create_model("my_vit_mini", img_size=384, depth=1)                                       # 577 tokens need head dim 64
     with pytest.raises(VitkError):
         m(torch.zeros(1, 3, 224, 224))                                                            # CPU input: no fallback
     assert m.no_weight_decay() == {"pos_embed", "cls_token", "dist_token"}

@@ -272,6 +272,38 @@ def test_label_out_of_range_gives_nan_not_a_wild_read(device):
     assert torch.isfinite(CrossEntropyLoss()(z.to(device), good.to(device))).item()
 
 
+@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 48), (2, 197, 4, 72), (1, 256, 1, 96), (3, 50, 2, 8), (1, 1, 1, 40), (1, 198, 2, 80)])
+def test_attention_other_head_dims(device, B, N, H, hd):
+    """head dims other than 64 (48 and 72 are my_vit_mini / my_vit_xs): the vector-arithmetic kernels against the oracle with the
+    same bf16 storage points, forward and backward (backward fed the kernel's own O and log-sum-exp), and against exact math"""
+    from oracle import ref_ops as R
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + N * 7 + H + hd)
+    D = H * hd
+    qkv = _randb((B, N, 3 * D), g, 1.5)
+    dout = _randb((B, N, D), g)
+    scale = hd ** -0.5
+    res = {}
+    for emu in (True, False):
+        q = qkv.float().requires_grad_(True)
+        o = R.attention(q, H, scale, emulate=emu)
+        o.backward(dout.float())
+        res[emu] = (o.detach(), q.grad)
+    out, lse = ops.attention_fwd(qkv.reshape(B * N, 3 * D).to(device), B, N, H, scale)
+    assert out.shape == (B * N, D)
+    assert rel_l2(out.float().reshape(B, N, D), res[True][0]) <= REL_TOL
+    assert rel_l2(out.float().reshape(B, N, D), res[False][0]) <= 6e-3
+    qh, kh, _ = qkv.float().reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    assert rel_l2(lse, torch.logsumexp(qh @ kh.transpose(-1, -2) * scale, dim=-1)) <= 1e-5
+    dqkv = ops.attention_bwd(qkv.reshape(B * N, 3 * D).to(device), out, dout.reshape(B * N, D).to(device), lse, B, N, H, scale)
+    got = dqkv.float().reshape(B, N, 3 * D)
+    want = R.attention_backward(qkv.float(), out.float().cpu().reshape(B, N, D), lse.cpu(), dout.float(), H, scale, emulate=True)
+    for which, name in enumerate("qkv"):
+        sl = slice(which * D, (which + 1) * D)
+        assert rel_l2(got[..., sl], rb(want[..., sl])) <= REL_TOL, name
+        assert rel_l2(got[..., sl], res[False][1][..., sl]) <= 1e-2, name
+
+
 def test_attention_matches_sdpa(device):
     """independent check of the kernel against torch's own scaled_dot_product_attention on CPU"""
     ops = _ops()

@@ -257,6 +257,21 @@ def test_real_width_models(device, name, B, depth):
     assert eall <= E2E_GRAD_TOL and cos >= 0.9995
 
 
+@pytest.mark.parametrize("name", ["my_vit_mini", "my_vit_xs"])
+def test_other_head_dim_models(device, name):
+    """the two sizes of models/my_vit.py whose heads are not 64 wide (144 / 3 = 48, 288 / 4 = 72): one training step, 3 blocks"""
+    ref, m = _pair(name, device, depth=3, global_pool="avg", dpr=0.1)
+    B = 4
+    x, y = _batch(B, 224, 40, 19)
+    ref.train()
+    scales = ref.make_drop_scales(B, generator=torch.Generator().manual_seed(6))
+    out, loss_ref, got, loss = _train_step_grads(ref, m, device, x, y, scales, emulate=True)
+    gv, rv = _gradvec(m, ref)
+    print(f"{name} (head dim {m.head_dim}): logits rel {rel_l2(got, out):.2e}, whole-gradient rel {rel_l2(gv, rv):.2e}")
+    assert rel_l2(got, out) <= E2E_TOL and abs(loss.item() - loss_ref.item()) <= E2E_TOL * abs(loss_ref.item())
+    assert rel_l2(gv, rv) <= E2E_GRAD_TOL
+
+
 def test_grad_accumulation_and_zero_grad(device):
     ref, m = _pair("vit_tiny_patch16_224", device, depth=2)
     x, y = _batch(4, 224, 40, 11)

@@ -45,6 +45,8 @@ SIGNATURES = {
     "vitk_attention_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
     "vitk_attention_bwd_workspace": (_sz, [_i, _i, _i]),
     "vitk_attention_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _sz, _p]),
+    "vitk_attention_generic_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "vitk_attention_generic_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "vitk_im2col_patches": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vitk_prefix_tokens_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vitk_pos_tokens_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

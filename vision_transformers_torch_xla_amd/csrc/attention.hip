@@ -530,3 +530,203 @@ int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Attention for head dims other than 64 (48 and 72 in the reference's my_vit_mini / my_vit_xs, models/my_vit.py:84-165): any
+// multiple of 8 up to 96, up to 256 tokens.  These are the small models, so this path is plain vector arithmetic, one thread
+// per query (or key) row with the whole row in registers and the other side's rows broadcast out of LDS - the same two-phase
+// plan and the same bf16 storage points as the MFMA kernels above (P and dS rounded before their products, O rounded on
+// output), fp32 everywhere else.  One workgroup of 256 threads per (batch, head); one wave per SIMD, so a thread may hold the
+// four rows of the backward's key phase (4 x 96 floats).
+#define GHD 96          // register rows are sized for this; the run-time head dim masks the rest
+#define GNMAX 256
+
+static __device__ __forceinline__ void g_load_row(const bf16_t* p, int hd, float (&r)[GHD]) {
+#pragma unroll
+    for (int c = 0; c < GHD / 8; ++c) {
+        if (c * 8 < hd) {
+            float t[8];
+            load8(p + c * 8, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[c * 8 + j] = t[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[c * 8 + j] = 0.f;
+        }
+    }
+}
+static __device__ __forceinline__ void g_store_row(bf16_t* p, int hd, const float (&r)[GHD]) {
+#pragma unroll
+    for (int c = 0; c < GHD / 8; ++c)
+        if (c * 8 < hd) {
+            const float t[8] = {r[c * 8], r[c * 8 + 1], r[c * 8 + 2], r[c * 8 + 3], r[c * 8 + 4], r[c * 8 + 5], r[c * 8 + 6], r[c * 8 + 7]};
+            store8(p + c * 8, t);
+        }
+}
+// dot of a register row with an LDS row (all lanes read the same address: broadcast), and axpy from an LDS row
+static __device__ __forceinline__ float g_dot(const float (&r)[GHD], const bf16_t* s, int hd) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < GHD / 8; ++c)
+        if (c * 8 < hd) {
+            float t[8];
+            load8(s + c * 8, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __builtin_fmaf(r[c * 8 + j], t[j], acc);
+        }
+    return acc;
+}
+static __device__ __forceinline__ void g_axpy(float a, const bf16_t* s, int hd, float (&r)[GHD]) {
+#pragma unroll
+    for (int c = 0; c < GHD / 8; ++c)
+        if (c * 8 < hd) {
+            float t[8];
+            load8(s + c * 8, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[c * 8 + j] = __builtin_fmaf(a, t[j], r[c * 8 + j]);
+        }
+}
+static __device__ __forceinline__ float g_round_bf16(float x) { return bf2f(f2bf(x)); }
+
+// rows [N][hd] of one (batch, head) slice of a [B*N, ld] tensor -> LDS [N][hd] (16-byte pieces)
+static __device__ __forceinline__ void g_fill(bf16_t* dst, const bf16_t* src, int ld, int N, int hd) {
+    const int cpr = hd / 8;
+    for (int i = threadIdx.x; i < N * cpr; i += blockDim.x) {
+        const int row = i / cpr, c = i - row * cpr;
+        *reinterpret_cast<uint4*>(dst + row * hd + c * 8) = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c * 8);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_generic_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                                  int N, int H, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(attn_smem);
+    bf16_t* Vs = Ks + N * hd;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * hd, ld = 3 * D;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * hd;
+    g_fill(Ks, base + D, ld, N, hd);
+    g_fill(Vs, base + 2 * D, ld, N, hd);
+    __syncthreads();
+    const int q = threadIdx.x;
+    if (q >= N) return;
+    float qr[GHD], o[GHD];
+    g_load_row(base + (size_t)q * ld, hd, qr);
+    float mx = -INFINITY;
+    for (int j = 0; j < N; ++j) mx = fmaxf(mx, g_dot(qr, Ks + j * hd, hd));
+    const float c2 = scale * 1.44269504088896340736f;
+#pragma unroll
+    for (int d = 0; d < GHD; ++d) o[d] = 0.f;
+    float sum = 0.f;
+    for (int j = 0; j < N; ++j) {
+        const float p = __builtin_amdgcn_exp2f((g_dot(qr, Ks + j * hd, hd) - mx) * c2);
+        sum += p;
+        g_axpy(g_round_bf16(p), Vs + j * hd, hd, o);
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int d = 0; d < GHD; ++d) o[d] *= inv;
+    g_store_row(out + ((size_t)b * N + q) * D + h * hd, hd, o);
+    lse[((size_t)b * H + h) * N + q] = (mx * c2 + __builtin_amdgcn_logf(sum)) * 0.69314718055994530942f;
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_generic_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                  bf16_t* __restrict__ dqkv, int N, int H, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+    bf16_t* R0 = reinterpret_cast<bf16_t*>(attn_smem);       // Q, then K
+    bf16_t* R1 = R0 + N * hd;                                 // dO, then V
+    float* lse_s = reinterpret_cast<float*>(R1 + N * hd);     // [N] lse * log2(e)
+    float* dl_s = lse_s + N;                                  // [N] rowsum(dO * O) * scale
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int D = H * hd, ld = 3 * D;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * hd;
+    const bf16_t* dobase = dout + (size_t)b * N * D + h * hd;
+    const bf16_t* obase = out + (size_t)b * N * D + h * hd;
+    const int t = threadIdx.x;
+    const float c2 = scale * 1.44269504088896340736f;
+    g_fill(R0, base, ld, N, hd);
+    g_fill(R1, dobase, D, N, hd);
+    if (t < N) {
+        float a[GHD], c[GHD];
+        g_load_row(dobase + (size_t)t * D, hd, a);
+        g_load_row(obase + (size_t)t * D, hd, c);
+        float part = 0.f;
+#pragma unroll
+        for (int d = 0; d < GHD; ++d) part = __builtin_fmaf(a[d], c[d], part);
+        dl_s[t] = part * scale;
+        lse_s[t] = lse[((size_t)b * H + h) * N + t] * 1.44269504088896340736f;
+    }
+    __syncthreads();
+    // phase 1: thread = key j.  dV[j] = sum_i bf16(P[i,j]) dO[i];  dK[j] = sum_i bf16(dS[i,j]) Q[i]
+    if (t < N) {
+        float kr[GHD], vr[GHD], dk[GHD], dv[GHD];
+        g_load_row(base + (size_t)t * ld + D, hd, kr);
+        g_load_row(base + (size_t)t * ld + 2 * D, hd, vr);
+#pragma unroll
+        for (int d = 0; d < GHD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        for (int i = 0; i < N; ++i) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(g_dot(kr, R0 + i * hd, hd), c2, -lse_s[i]));
+            const float ds = p * __builtin_fmaf(g_dot(vr, R1 + i * hd, hd), scale, -dl_s[i]);
+            g_axpy(g_round_bf16(p), R1 + i * hd, hd, dv);
+            g_axpy(g_round_bf16(ds), R0 + i * hd, hd, dk);
+        }
+        bf16_t* rowp = dqkv + ((size_t)b * N + t) * ld + h * hd;
+        g_store_row(rowp + D, hd, dk);
+        g_store_row(rowp + 2 * D, hd, dv);
+    }
+    __syncthreads();
+    g_fill(R0, base + D, ld, N, hd);
+    g_fill(R1, base + 2 * D, ld, N, hd);
+    __syncthreads();
+    // phase 2: thread = query i.  dQ[i] = sum_j bf16(dS[i,j]) K[j]
+    if (t < N) {
+        float qr[GHD], dor[GHD], dq[GHD];
+        g_load_row(base + (size_t)t * ld, hd, qr);
+        g_load_row(dobase + (size_t)t * D, hd, dor);
+#pragma unroll
+        for (int d = 0; d < GHD; ++d) dq[d] = 0.f;
+        const float nl = -lse_s[t], dl = dl_s[t];
+        for (int j = 0; j < N; ++j) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(g_dot(qr, R0 + j * hd, hd), c2, nl));
+            const float ds = p * __builtin_fmaf(g_dot(dor, R1 + j * hd, hd), scale, -dl);
+            g_axpy(g_round_bf16(ds), R0 + j * hd, hd, dq);
+        }
+        g_store_row(dqkv + ((size_t)b * N + t) * ld + h * hd, hd, dq);
+    }
+}
+
+extern "C" {
+
+int vitk_attention_generic_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int head_dim, float scale, void* stream) {
+    VITK_REQUIRE(qkv && out && lse, "attention_generic_fwd: null pointer");
+    VITK_REQUIRE(B > 0 && H > 0 && N > 0 && N <= GNMAX, "attention_generic_fwd: need B,H>0 and 0<N<=%d (B=%d N=%d H=%d)", GNMAX, B, N, H);
+    VITK_REQUIRE(head_dim >= 8 && head_dim <= GHD && head_dim % 8 == 0, "attention_generic_fwd: head dim %d must be a multiple of 8 in [8, %d]",
+                 head_dim, GHD);
+    VITK_REQUIRE(vitk_aligned(qkv, 16) && vitk_aligned(out, 16), "attention_generic_fwd: pointers must be 16-byte aligned");
+    const size_t smem = (size_t)2 * N * head_dim * sizeof(bf16_t);
+    static VitkLdsOnce once = {};
+    if (int rc_ = vitk_lds_once(once, (const void*)attn_fwd_generic_kernel, (size_t)2 * GNMAX * GHD * sizeof(bf16_t), "attention_generic_fwd")) return rc_;
+    attn_fwd_generic_kernel<<<B * H, 256, smem, (hipStream_t)stream>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, head_dim, scale);
+    return vitk_check_launch("attention_generic_fwd");
+}
+
+int vitk_attention_generic_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N, int H,
+                               int head_dim, float scale, void* stream) {
+    VITK_REQUIRE(qkv && out && dout && lse && dqkv, "attention_generic_bwd: null pointer");
+    VITK_REQUIRE(B > 0 && H > 0 && N > 0 && N <= GNMAX, "attention_generic_bwd: need B,H>0 and 0<N<=%d (B=%d N=%d H=%d)", GNMAX, B, N, H);
+    VITK_REQUIRE(head_dim >= 8 && head_dim <= GHD && head_dim % 8 == 0, "attention_generic_bwd: head dim %d must be a multiple of 8 in [8, %d]",
+                 head_dim, GHD);
+    VITK_REQUIRE(vitk_aligned(qkv, 16) && vitk_aligned(out, 16) && vitk_aligned(dout, 16) && vitk_aligned(dqkv, 16),
+                 "attention_generic_bwd: pointers must be 16-byte aligned");
+    const size_t smem = (size_t)2 * N * head_dim * sizeof(bf16_t) + (size_t)2 * N * sizeof(float);
+    static VitkLdsOnce once = {};
+    if (int rc_ = vitk_lds_once(once, (const void*)attn_bwd_generic_kernel, (size_t)2 * GNMAX * GHD * sizeof(bf16_t) + 2 * GNMAX * sizeof(float),
+                                "attention_generic_bwd"))
+        return rc_;
+    attn_bwd_generic_kernel<<<B * H, 256, smem, (hipStream_t)stream>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                                                                      (bf16_t*)dqkv, N, H, head_dim, scale);
+    return vitk_check_launch("attention_generic_bwd");
+}
+
+}  // extern "C"

@@ -162,20 +162,36 @@ def gemm_tn(a, b, out, *, dbias=None, accumulate=False, ws: Workspace = None):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+def _head_dim(qkv, B, N, H):
+    if qkv.dim() != 2 or qkv.shape[0] != B * N or qkv.shape[1] % (3 * H):
+        raise _lib.VitkError(f"attention: qkv must be [B*N, 3*H*head_dim] = [{B * N}, 3*{H}*d], got {tuple(qkv.shape)}")
+    return qkv.shape[1] // (3 * H)
+
+
 def attention_fwd(qkv, B, N, H, scale):
-    """qkv bf16 [B*N, 3*H*64] -> (out bf16 [B*N, H*64], lse fp32 [B,H,N])"""
+    """qkv bf16 [B*N, 3*H*d] -> (out bf16 [B*N, H*d], lse fp32 [B,H,N]).  d = 64: the MFMA kernels (<= 608 tokens); any other
+    multiple of 8 up to 96: the vector-arithmetic kernels (<= 256 tokens)."""
     _chk(qkv, bf16, "qkv")
-    out = torch.empty((B * N, H * 64), dtype=bf16, device=qkv.device)
+    d = _head_dim(qkv, B, N, H)
+    out = torch.empty((B * N, H * d), dtype=bf16, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=f32, device=qkv.device)
-    check(_lib.load().vitk_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, N, H, scale, _stream()), "attention_fwd")
+    if d == 64:
+        check(_lib.load().vitk_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, N, H, scale, _stream()), "attention_fwd")
+    else:
+        check(_lib.load().vitk_attention_generic_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, N, H, d, scale, _stream()), "attention_generic_fwd")
     return out, lse
 
 
 def attention_bwd(qkv, out, dout, lse, B, N, H, scale, ws: Workspace = None, dqkv=None):
     _chk(qkv, bf16, "qkv"); _chk(out, bf16, "out"); _chk(dout, bf16, "dout"); _chk(lse, f32, "lse")
+    d = _head_dim(qkv, B, N, H)
     lib = _lib.load()
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
+    if d != 64:
+        check(lib.vitk_attention_generic_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, N, H, d, scale, _stream()),
+              "attention_generic_bwd")
+        return dqkv
     need = lib.vitk_attention_bwd_workspace(B, N, H)
     w = (ws or _default_ws).get(need, qkv.device) if need else None
     check(lib.vitk_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, N, H, scale, _ptr(w),

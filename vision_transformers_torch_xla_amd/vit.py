@@ -219,8 +219,8 @@ class VisionTransformer(nn.Module):
             raise VitkError("distilled models require global_pool='token' (models/deit.py:38)")
         if not qkv_bias:
             raise VitkError("qkv_bias=False not implemented")
-        if embed_dim % num_heads or embed_dim // num_heads != 64:
-            raise VitkError(f"the fused attention kernel supports head dim 64 only (embed_dim={embed_dim}, heads={num_heads})")
+        if embed_dim % num_heads or (embed_dim // num_heads) % 8 or embed_dim // num_heads > 96:
+            raise VitkError(f"head dim must be a multiple of 8 up to 96 (embed_dim={embed_dim}, heads={num_heads}: {embed_dim / num_heads:g})")
         if patch_size % 8 or img_size % patch_size:
             raise VitkError("patch_size must be a multiple of 8 and divide img_size")
         if num_classes % 8:
@@ -239,8 +239,12 @@ class VisionTransformer(nn.Module):
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
         self.num_patches = self.patch_embed.num_patches
         self.num_tokens = self.num_patches + self.num_prefix_tokens
-        if self.num_tokens > 608:
-            raise VitkError(f"{self.num_tokens} tokens exceed the fused attention kernel's limit (608)")
+        self.head_dim = embed_dim // num_heads
+        # head dim 64 runs on the MFMA attention kernels (up to 608 tokens); the other head dims of the reference's size table
+        # (48, 72: models/my_vit.py:84-165) on the vector-arithmetic kernels (up to 256 tokens)
+        limit = 608 if self.head_dim == 64 else 256
+        if self.num_tokens > limit:
+            raise VitkError(f"{self.num_tokens} tokens exceed the attention kernels' limit for head dim {self.head_dim} ({limit})")
         # registration order = timm's named_parameters() order (cls_token, pos_embed, dist_token: models/deit.py:41-43 adds the
         # distillation token after the base class registered the other two), which optimizer state dicts are matched by
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
@@ -503,7 +507,7 @@ class VisionTransformer(nn.Module):
         N, D, H, npre, P = self.num_tokens, self.embed_dim, self.num_heads, self.num_prefix_tokens, self.num_patches
         M = B * N
         wb = self._wb
-        scale = 64 ** -0.5
+        scale = self.head_dim ** -0.5
         patches = ops.im2col_patches(img, self.patch_size)
         x = torch.empty((M, D), dtype=bf16, device=img.device)
         ops.gemm_nt(patches, wb["patch_embed.proj.weight"], epilogue=EPI_PATCH, bias=self.patch_embed.proj.bias, out=x,
@@ -616,7 +620,7 @@ class VisionTransformer(nn.Module):
         H = self.num_heads
         M = B * N
         wb, wt, g, ws = self._wb, self._wt, self._gview, self._ws
-        scale = 64 ** -0.5
+        scale = self.head_dim ** -0.5
         self._ensure_grad_buffer()
         g = self._gview
         # grads: overwrite unless a previous backward since the last zero_grad already wrote the buffer
