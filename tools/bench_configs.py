@@ -25,8 +25,8 @@ WORKLOADS = {
     "vit_b_384": ("vit_base_patch16_384", 128, 384, 332.91, None),
     # the reference's CPU-runnable case and its small sizes (models/my_vit.py:84-165; head dims 48 / 64 / 72)
     "vit_tiny_224": ("vit_tiny_patch16_224", 512, 224, 7.52, None),
-    "my_vit_mini": ("my_vit_mini", 512, 224, 4.40, None),
-    "my_vit_xs": ("my_vit_xs", 512, 224, 16.29, None),
+    "my_vit_mini": ("my_vit_mini", 512, 224, 4.47, None),
+    "my_vit_xs": ("my_vit_xs", 512, 224, 15.99, None),
     "deit_b_kd": ("deit_base_distilled_patch16_224", 512, 224, 105.94 + 35.13, "vit_base_patch16_224"),
     # the reference's default recipe (main.py:219-229, run_train.sh:64-65): Mixup 0.8 / CutMix 1.0 on the device, soft-target CE, EMA
     "vit_b_224_recipe": ("vit_base_patch16_224", 512, 224, 105.38, "recipe"),

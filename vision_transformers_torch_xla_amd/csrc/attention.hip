@@ -538,9 +538,10 @@ int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const
 // plan and the same bf16 storage points as the MFMA kernels above (P and dS rounded before their products, O rounded on
 // output), fp32 everywhere else.  One workgroup of 256 threads per (batch, head); one wave per SIMD, so a thread may hold the
 // four rows of the backward's key phase (4 x 96 floats).
-#define GHD 96          // register rows are sized for this; the run-time head dim masks the rest
+#define GHDMAX 96       // largest head dim; register rows are sized by the template parameter GHD (48 or 96) >= the run-time head dim
 #define GNMAX 256
 
+template <int GHD>
 static __device__ __forceinline__ void g_load_row(const bf16_t* p, int hd, float (&r)[GHD]) {
 #pragma unroll
     for (int c = 0; c < GHD / 8; ++c) {
@@ -555,6 +556,7 @@ static __device__ __forceinline__ void g_load_row(const bf16_t* p, int hd, float
         }
     }
 }
+template <int GHD>
 static __device__ __forceinline__ void g_store_row(bf16_t* p, int hd, const float (&r)[GHD]) {
 #pragma unroll
     for (int c = 0; c < GHD / 8; ++c)
@@ -564,6 +566,7 @@ static __device__ __forceinline__ void g_store_row(bf16_t* p, int hd, const floa
         }
 }
 // dot of a register row with an LDS row (all lanes read the same address: broadcast), and axpy from an LDS row
+template <int GHD>
 static __device__ __forceinline__ float g_dot(const float (&r)[GHD], const bf16_t* s, int hd) {
     float acc = 0.f;
 #pragma unroll
@@ -576,6 +579,7 @@ static __device__ __forceinline__ float g_dot(const float (&r)[GHD], const bf16_
         }
     return acc;
 }
+template <int GHD>
 static __device__ __forceinline__ void g_axpy(float a, const bf16_t* s, int hd, float (&r)[GHD]) {
 #pragma unroll
     for (int c = 0; c < GHD / 8; ++c)
@@ -597,7 +601,8 @@ static __device__ __forceinline__ void g_fill(bf16_t* dst, const bf16_t* src, in
     }
 }
 
-__global__ __launch_bounds__(256, 1) void attn_fwd_generic_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+template <int GHD>
+__global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
                                                                   int N, int H, int hd, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(attn_smem);
@@ -613,11 +618,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_generic_kernel(const bf16_t* 
     float qr[GHD], o[GHD];
     g_load_row(base + (size_t)q * ld, hd, qr);
     float mx = -INFINITY;
-    for (int j = 0; j < N; ++j) mx = fmaxf(mx, g_dot(qr, Ks + j * hd, hd));
+#pragma unroll 4
+    for (int j = 0; j < N; ++j) mx = fmaxf(mx, g_dot(qr, Ks + j * hd, hd));      // unrolled: four keys' LDS reads in flight per thread
     const float c2 = scale * 1.44269504088896340736f;
 #pragma unroll
     for (int d = 0; d < GHD; ++d) o[d] = 0.f;
     float sum = 0.f;
+#pragma unroll 4
     for (int j = 0; j < N; ++j) {
         const float p = __builtin_amdgcn_exp2f((g_dot(qr, Ks + j * hd, hd) - mx) * c2);
         sum += p;
@@ -630,7 +637,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_generic_kernel(const bf16_t* 
     lse[((size_t)b * H + h) * N + q] = (mx * c2 + __builtin_amdgcn_logf(sum)) * 0.69314718055994530942f;
 }
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_generic_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+template <int GHD>
+__global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                   const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                   bf16_t* __restrict__ dqkv, int N, int H, int hd, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
@@ -665,6 +673,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_generic_kernel(const bf16_t* 
         g_load_row(base + (size_t)t * ld + 2 * D, hd, vr);
 #pragma unroll
         for (int d = 0; d < GHD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+#pragma unroll 2
         for (int i = 0; i < N; ++i) {
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(g_dot(kr, R0 + i * hd, hd), c2, -lse_s[i]));
             const float ds = p * __builtin_fmaf(g_dot(vr, R1 + i * hd, hd), scale, -dl_s[i]);
@@ -687,6 +696,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_generic_kernel(const bf16_t* 
 #pragma unroll
         for (int d = 0; d < GHD; ++d) dq[d] = 0.f;
         const float nl = -lse_s[t], dl = dl_s[t];
+#pragma unroll 4
         for (int j = 0; j < N; ++j) {
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(g_dot(qr, R0 + j * hd, hd), c2, nl));
             const float ds = p * __builtin_fmaf(g_dot(dor, R1 + j * hd, hd), scale, -dl);
@@ -701,13 +711,20 @@ extern "C" {
 int vitk_attention_generic_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int head_dim, float scale, void* stream) {
     VITK_REQUIRE(qkv && out && lse, "attention_generic_fwd: null pointer");
     VITK_REQUIRE(B > 0 && H > 0 && N > 0 && N <= GNMAX, "attention_generic_fwd: need B,H>0 and 0<N<=%d (B=%d N=%d H=%d)", GNMAX, B, N, H);
-    VITK_REQUIRE(head_dim >= 8 && head_dim <= GHD && head_dim % 8 == 0, "attention_generic_fwd: head dim %d must be a multiple of 8 in [8, %d]",
-                 head_dim, GHD);
+    VITK_REQUIRE(head_dim >= 8 && head_dim <= GHDMAX && head_dim % 8 == 0, "attention_generic_fwd: head dim %d must be a multiple of 8 in [8, %d]",
+                 head_dim, GHDMAX);
     VITK_REQUIRE(vitk_aligned(qkv, 16) && vitk_aligned(out, 16), "attention_generic_fwd: pointers must be 16-byte aligned");
     const size_t smem = (size_t)2 * N * head_dim * sizeof(bf16_t);
-    static VitkLdsOnce once = {};
-    if (int rc_ = vitk_lds_once(once, (const void*)attn_fwd_generic_kernel, (size_t)2 * GNMAX * GHD * sizeof(bf16_t), "attention_generic_fwd")) return rc_;
-    attn_fwd_generic_kernel<<<B * H, 256, smem, (hipStream_t)stream>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, head_dim, scale);
+#define VITK_GFWD(G)                                                                                                                  \
+    {                                                                                                                                 \
+        static VitkLdsOnce once = {};                                                                                                 \
+        if (int rc_ = vitk_lds_once(once, (const void*)attn_fwd_generic_kernel<G>, (size_t)2 * GNMAX * GHDMAX * sizeof(bf16_t),       \
+                                    "attention_generic_fwd"))                                                                        \
+            return rc_;                                                                                                               \
+        attn_fwd_generic_kernel<G><<<B * H, 256, smem, (hipStream_t)stream>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, head_dim, scale); \
+    }
+    if (head_dim <= 48) VITK_GFWD(48) else VITK_GFWD(96)      // (a 72-wide instantiation measured slower than the 96-wide one: 1 wave per SIMD either way)
+#undef VITK_GFWD
     return vitk_check_launch("attention_generic_fwd");
 }
 
@@ -715,17 +732,22 @@ int vitk_attention_generic_bwd(const void* qkv, const void* out, const void* dou
                                int head_dim, float scale, void* stream) {
     VITK_REQUIRE(qkv && out && dout && lse && dqkv, "attention_generic_bwd: null pointer");
     VITK_REQUIRE(B > 0 && H > 0 && N > 0 && N <= GNMAX, "attention_generic_bwd: need B,H>0 and 0<N<=%d (B=%d N=%d H=%d)", GNMAX, B, N, H);
-    VITK_REQUIRE(head_dim >= 8 && head_dim <= GHD && head_dim % 8 == 0, "attention_generic_bwd: head dim %d must be a multiple of 8 in [8, %d]",
-                 head_dim, GHD);
+    VITK_REQUIRE(head_dim >= 8 && head_dim <= GHDMAX && head_dim % 8 == 0, "attention_generic_bwd: head dim %d must be a multiple of 8 in [8, %d]",
+                 head_dim, GHDMAX);
     VITK_REQUIRE(vitk_aligned(qkv, 16) && vitk_aligned(out, 16) && vitk_aligned(dout, 16) && vitk_aligned(dqkv, 16),
                  "attention_generic_bwd: pointers must be 16-byte aligned");
     const size_t smem = (size_t)2 * N * head_dim * sizeof(bf16_t) + (size_t)2 * N * sizeof(float);
-    static VitkLdsOnce once = {};
-    if (int rc_ = vitk_lds_once(once, (const void*)attn_bwd_generic_kernel, (size_t)2 * GNMAX * GHD * sizeof(bf16_t) + 2 * GNMAX * sizeof(float),
-                                "attention_generic_bwd"))
-        return rc_;
-    attn_bwd_generic_kernel<<<B * H, 256, smem, (hipStream_t)stream>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
-                                                                      (bf16_t*)dqkv, N, H, head_dim, scale);
+#define VITK_GBWD(G)                                                                                                                  \
+    {                                                                                                                                 \
+        static VitkLdsOnce once = {};                                                                                                 \
+        if (int rc_ = vitk_lds_once(once, (const void*)attn_bwd_generic_kernel<G>,                                                    \
+                                    (size_t)2 * GNMAX * GHDMAX * sizeof(bf16_t) + 2 * GNMAX * sizeof(float), "attention_generic_bwd"))  \
+            return rc_;                                                                                                               \
+        attn_bwd_generic_kernel<G><<<B * H, 256, smem, (hipStream_t)stream>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, \
+                                                                             (bf16_t*)dqkv, N, H, head_dim, scale);                  \
+    }
+    if (head_dim <= 48) VITK_GBWD(48) else VITK_GBWD(96)
+#undef VITK_GBWD
     return vitk_check_launch("attention_generic_bwd");
 }
 
