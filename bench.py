@@ -189,6 +189,7 @@ def main():
 
     torch.manual_seed(0)                                       # identical init on every rank (plus rank-0 broadcast)
     core = create_model(args.model, pretrained=False, num_classes=1000, global_pool="avg", drop_path_rate=0.1).to(device)
+    torch.manual_seed(0 + rank)                                # main.py:405: every rank draws its own stochastic-depth masks
     bucket = int(os.environ.get("VITK_DP_BUCKET_MB", "32")) << 20
     model = (DistributedDataParallel(core, device_ids=[local], bucket_bytes=bucket, single_rank_collectives=force_dist)
              if (world > 1 or force_dist) else core)
