@@ -10,9 +10,9 @@ import torch
 from vision_transformers_torch_xla_amd import _lib, ops
 
 M = 512 * 197
-NT = [("qkv fwd", M, 2304, 768, _lib.EPI_BIAS), ("proj fwd", M, 768, 768, _lib.EPI_BIAS_RES), ("fc1 fwd", M, 3072, 768, _lib.EPI_BIAS_GELU),
+NT = [("qkv fwd", M, 2304, 768, _lib.EPI_BIAS), ("proj fwd", M, 768, 768, _lib.EPI_BIAS_RES), ("fc1 fwd", M, 3072, 768, _lib.EPI_BIAS_GELU_DG),
       ("fc2 fwd", M, 768, 3072, _lib.EPI_BIAS_RES), ("dqkv->dy", M, 768, 2304, _lib.EPI_PLAIN), ("dproj->do", M, 768, 768, _lib.EPI_PLAIN),
-      ("dfc2->dh", M, 3072, 768, _lib.EPI_DGELU), ("dfc1->dy", M, 768, 3072, _lib.EPI_PLAIN)]
+      ("dfc2->dh", M, 3072, 768, _lib.EPI_MUL), ("dfc1->dy", M, 768, 3072, _lib.EPI_PLAIN)]
 TN = [("qkv wgrad", M, 2304, 768), ("proj wgrad", M, 768, 768), ("fc1 wgrad", M, 3072, 768), ("fc2 wgrad", M, 768, 3072)]
 
 
@@ -40,8 +40,8 @@ def main():
             a, b = rnd(m, k), rnd(n, k)
             bias = torch.randn(n, device=dev)
             res = rnd(m, n) if epi == _lib.EPI_BIAS_RES else None
-            aux = rnd(m, n) if epi == _lib.EPI_DGELU else None
-            out2 = torch.empty((m, n), dtype=torch.bfloat16, device=dev) if epi == _lib.EPI_BIAS_GELU else None
+            aux = rnd(m, n) if epi in (_lib.EPI_DGELU, _lib.EPI_MUL) else None
+            out2 = torch.empty((m, n), dtype=torch.bfloat16, device=dev) if epi in (_lib.EPI_BIAS_GELU, _lib.EPI_BIAS_GELU_DG) else None
             out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
             ms = timeit(lambda: ops.gemm_nt(a, b, epilogue=epi, bias=bias, res=res, aux=aux, out2=out2, out=out), reps)
             print(f"nt {name:10s} M={m} N={n:5d} K={k:5d}  {ms:7.3f} ms  {2.0 * m * n * k / ms / 1e9:7.1f} TFLOP/s", flush=True)

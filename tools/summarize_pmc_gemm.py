@@ -51,8 +51,11 @@ def main():
     for k in kernels:
         a = {c: acc[k][c][1] / acc[k][c][0] for c in acc[k] if acc[k][c][0]}
         parts = []
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in a and "SQ_BUSY_CYCLES" in a and a["SQ_BUSY_CYCLES"]:
-            parts.append(f"MFMA busy / SQ busy = {a['SQ_VALU_MFMA_BUSY_CYCLES'] / a['SQ_BUSY_CYCLES']:.2f}")
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in a and a.get("GRBM_GUI_ACTIVE"):
+            cyc = a["GRBM_GUI_ACTIVE"] / 8.0                      # the counter sums the 8 XCDs
+            us = dur[k][1] / max(dur[k][0], 1)
+            parts.append(f"matrix pipe busy {100 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * cyc):.0f} % of the launch's cycles on 1 024 SIMDs "
+                         f"({a['SQ_VALU_MFMA_BUSY_CYCLES'] / a['SQ_INSTS_MFMA']:.1f} cycles per MFMA; clock {cyc / us / 1e3:.2f} GHz)")
         if "SQ_WAIT_INST_ANY" in a and "SQ_WAVE_CYCLES" in a and a["SQ_WAVE_CYCLES"]:
             parts.append(f"issue-stalled {100 * a['SQ_WAIT_INST_ANY'] / a['SQ_WAVE_CYCLES']:.0f} % of wave cycles")
         if "SQ_WAIT_ANY" in a and "SQ_WAVE_CYCLES" in a and a["SQ_WAVE_CYCLES"]:
