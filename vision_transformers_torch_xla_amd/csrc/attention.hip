@@ -15,6 +15,9 @@ bool vitk_prof_begin(void* stream, double flop, int kind);
 void vitk_prof_end(void* stream);
 
 #define HD 64   // head dim
+#ifndef VITK_ATTN_OWN
+#define VITK_ATTN_OWN 1
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
@@ -229,12 +232,61 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             glds16_v(src, lds0 + (unsigned)pc * 1024u);
         }
     };
+    // this wave's own K, V rows of a key tile (phase 1), straight from global memory as MFMA fragments
+    auto load_kv = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2]) {
+        int key = kt * 16 + lr;
+        key = key < N ? key : N - 1;
+        const bf16_t* kp = base + (size_t)key * ld + D + 8 * lg;
+        kf[0] = *reinterpret_cast<const bf16x8*>(kp);
+        kf[1] = *reinterpret_cast<const bf16x8*>(kp + 32);
+        vf[0] = *reinterpret_cast<const bf16x8*>(kp + D);
+        vf[1] = *reinterpret_cast<const bf16x8*>(kp + D + 32);
+    };
+    // Up to 224 tokens a wave owns at most two tiles per phase (OWN): nothing that sits in LDS is fetched from global memory a
+    // second time - delta takes dO from the LDS image, and the wave's own Q, dO fragments of phase 2 are read out of the
+    // images before K and V replace them - and the first own K, V fragments travel with the fill.
+    constexpr int TOT = NPAD * 8, STR = WAVES * 64;
+    constexpr bool OWN = VITK_ATTN_OWN && TOT % STR == 0 && TOT / STR <= 4 && TPW <= 2;
+    bf16x8 kf[2], vf[2];
+    if constexpr (OWN) load_kv(wave, kf, vf);
     fill(false);
     // delta and lse: item = (query row, 16-byte chunk), 8 neighbouring lanes share a row.  Up to 224 tokens NPAD * 8 items are
     // an exact multiple of the block size and all loads of a thread are issued before the first is used; beyond, a plain loop
     // (every trip is taken by whole 8-lane groups, so the shuffles stay inside active lanes).
-    constexpr int TOT = NPAD * 8, STR = WAVES * 64;
-    if constexpr (TOT % STR == 0 && TOT / STR <= 4) {
+    if constexpr (OWN) {
+        constexpr int ITEMS = TOT / STR;
+        u32x4_t rc[ITEMS];
+        float lv[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int it = tid + i * STR;
+            int q = it >> 3;
+            q = q < N ? q : N - 1;
+            rc[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(obase + (size_t)q * D + (it & 7) * 8));
+            lv[i] = lse[((size_t)b * H + h) * N + q];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int it = tid + i * STR;
+            const int q = it >> 3;
+            const u32x4_t ra = *reinterpret_cast<const u32x4_t*>(R1 + q * HD + (((it & 7) ^ (q & 7)) << 3));
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part += __uint_as_float(ra[j] << 16) * __uint_as_float(rc[i][j] << 16);
+                part += __uint_as_float(ra[j] & 0xffff0000u) * __uint_as_float(rc[i][j] & 0xffff0000u);
+            }
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if ((it & 7) == 0) {
+                dl_s[q] = part * scale;
+                lse_s[q] = q < N ? lv[i] * 1.44269504088896340736f : INFINITY;
+            }
+        }
+    } else if constexpr (TOT % STR == 0 && TOT / STR <= 4) {
         constexpr int ITEMS = TOT / STR;
         u32x4_t ra[ITEMS], rc[ITEMS];
         float lv[ITEMS];
@@ -300,16 +352,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
     // ---------------------------------------------------------------- phase 1: dK, dV of the owned key tiles (R0 = Q, R1 = dO)
 #pragma unroll 1
     for (int kt = wave; kt < MAXT; kt += WAVES) {
-        bf16x8 kf[2], vf[2];
-        {
-            int key = kt * 16 + lr;
-            key = key < N ? key : N - 1;
-            const bf16_t* kp = base + (size_t)key * ld + D + 8 * lg;
-            kf[0] = *reinterpret_cast<const bf16x8*>(kp);
-            kf[1] = *reinterpret_cast<const bf16x8*>(kp + 32);
-            vf[0] = *reinterpret_cast<const bf16x8*>(kp + D);
-            vf[1] = *reinterpret_cast<const bf16x8*>(kp + D + 32);
-        }
+        if (!OWN || kt != wave) load_kv(kt, kf, vf);
         f32x4 dv[4], dk[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -377,12 +420,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             *reinterpret_cast<u32x4_t*>(rowp + 2 * D + pair_col(2, 3, lg)) = v23;
         }
     }
-    (void)TPW;
 
-    // every wave is done with Q and dO: refill the same LDS with K and V
-    __syncthreads();
-    fill(true);
-    // this wave's first query tile travels with the refill
+    // this wave's own Q, dO fragments of phase 2: out of the LDS images while they still hold Q and dO (OWN), else from global
     auto load_q = [&](int qt, bf16x8 (&qf)[2], bf16x8 (&dof)[2]) {
         int q = qt * 16 + lr;
         q = q < N ? q : N - 1;
@@ -393,8 +432,22 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         dof[0] = *reinterpret_cast<const bf16x8*>(dp);
         dof[1] = *reinterpret_cast<const bf16x8*>(dp + 32);
     };
-    bf16x8 qf[2], dof[2];
-    load_q(wave, qf, dof);
+    auto lds_q = [&](int qt, bf16x8 (&qf)[2], bf16x8 (&dof)[2]) {
+        qf[0] = *reinterpret_cast<const bf16x8*>(R0 + qt * 16 * HD + foff0);
+        qf[1] = *reinterpret_cast<const bf16x8*>(R0 + qt * 16 * HD + foff1);
+        dof[0] = *reinterpret_cast<const bf16x8*>(R1 + qt * 16 * HD + foff0);
+        dof[1] = *reinterpret_cast<const bf16x8*>(R1 + qt * 16 * HD + foff1);
+    };
+    bf16x8 qf[2], dof[2], qf2[2], dof2[2];
+    if constexpr (OWN) {
+        lds_q(wave, qf, dof);
+        if constexpr (TPW == 2) lds_q(wave + WAVES < MAXT ? wave + WAVES : wave, qf2, dof2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // every wave is done with Q and dO: refill the same LDS with K and V
+    __syncthreads();
+    fill(true);
+    if constexpr (!OWN) load_q(wave, qf, dof);      // the first query tile travels with the refill
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -448,7 +501,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if ((qt + WAVES) * 16 < N) load_q(qt + WAVES, qf, dof);
+        if constexpr (!OWN) {
+            if ((qt + WAVES) * 16 < N) load_q(qt + WAVES, qf, dof);
+        }
         // dq[dt][r] = dQ^T[d = 16dt + 4lg + r][q = lr]
         uint2 pq[4];
 #pragma unroll
@@ -462,6 +517,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             *reinterpret_cast<u32x4_t*>(rowp + pair_col(0, 1, lg)) = q01;
             *reinterpret_cast<u32x4_t*>(rowp + pair_col(2, 3, lg)) = q23;
         }
+        if constexpr (OWN && TPW == 2) { qf[0] = qf2[0]; qf[1] = qf2[1]; dof[0] = dof2[0]; dof[1] = dof2[1]; }
     }
 }
 
