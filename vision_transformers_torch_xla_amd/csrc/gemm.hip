@@ -42,8 +42,6 @@ struct GemmNTParams {
     const float* pos; int patches; int prefix;
     int tiles_n; int num_tiles;
     const int* smap; int rps;     // BIAS_RES only: output / residual row of GEMM row m is smap[m / rps] * rps + m % rps
-    int stagger_mode;             // 0: the odd XCDs wait, 1: the workgroups with one tile fewer than the others wait
-    int stagger;                  // persistent kernels: workgroups of the odd XCDs start this many sleeps (about 1 us each) late
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Remap so that every XCD works on a
@@ -403,8 +401,6 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
     const int G = gridDim.x;
     int v = blockIdx.x;
     int m0, n0, nm0 = 0, nn0 = 0;
-    if (p.stagger > 0 && (p.stagger_mode ? (int)blockIdx.x >= p.num_tiles % G : (int)(blockIdx.x & 1)))
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(32);
     aim(v, m0, n0);
     stageA(0, 0);
     stageB(0, 0);
@@ -546,279 +542,6 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         m0 = nm0;
         n0 = nn0;
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// gemm_nt, large-tile persistent variant with FOUR waves: the same 256x256 tile, LDS image, DMA staging, K-step stream and
-// epilogue plan as gemm_ntp_kernel, but one wave per SIMD, each a 128x128 sub-tile = 8x8 MFMA tiles = 256 accumulator
-// registers.  A K-step then reads 128 KB of fragments out of LDS instead of 192 KB (each A and B row is read by two waves, not
-// by four and two), and a wave issues 128 MFMAs per K-step in 8 phases of 16: phase (ks, q) multiplies A row tiles 2q, 2q+1 of
-// K-slice ks with the 8 B fragments of the slice; the A fragments of the next phase and, through slice 0, the B fragments of
-// slice 1 are read while it runs; the last phase reads slice 0 of the next K-step out of the other buffer.
-#define NTQ_DRAIN 32                 // output stores a wave issues per full tile, at least
-#define NTQ_LDS (4 * LTILE * 2 + 4 * 16 * 128 * 4)   // bytes: operand image + 8 KB of epilogue staging per wave = 160 KB
-#ifndef NTQ_PREFETCH
-#define NTQ_PREFETCH 0               // K-steps ahead of the MFMAs at which the activation panel is prefetched into L2 (0: off)
-#endif
-#ifndef NTQ_SPREAD
-#define NTQ_SPREAD 4                 // phases over which the 16 DMA instructions of a K-step request are issued (2 or 4)
-#endif
-
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_ntq_kernel(const GemmNTParams p) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t lsm[];   // [2 buffers][A tile | B tile], [4 waves][16][128] fp32
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 15, lg = lane >> 4;
-    float* stg = reinterpret_cast<float*>(lsm + 4 * LTILE) + wave * (16 * 128);
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lsm));
-
-    // staging: wave w, piece j (0..7) covers rows (w*8+j)*8 .. +7 of a tile; lane -> row += lane/8, LDS position lane%8, which
-    // receives source chunk (lane%8) ^ (row&7); row&7 == lane/8 for every piece
-    const int srow = lane >> 3, sch = (lane & 7) ^ srow;
-    const unsigned lds_stage = (unsigned)(wave * 8 * 8 * GBK * sizeof(bf16_t));
-    const bf16_t* sA = p.A;
-    const bf16_t* sB = p.B;
-    unsigned voA[8], voB[8];
-    auto aim = [&](int v, int& m0, int& n0) {
-        const int tile = xcd_remap(v, p.num_tiles);
-        const int tm_ = tile / p.tiles_n;
-        m0 = tm_ * LBM;
-        n0 = (tile - tm_ * p.tiles_n) * LBN;
-        sA = p.A + (size_t)m0 * p.lda;
-        sB = p.B + (size_t)n0 * p.ldb;
-        const int ra_max = p.M - 1 - m0, rb_max = p.N - 1 - n0;       // rows past the edge re-read the last valid row
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = (wave * 8 + j) * 8 + srow;
-            const int ra = row < ra_max ? row : ra_max, rb = row < rb_max ? row : rb_max;
-            voA[j] = (unsigned)((ra * p.lda + sch * 8) * (int)sizeof(bf16_t));
-            voB[j] = (unsigned)((rb * p.ldb + sch * 8) * (int)sizeof(bf16_t));
-        }
-    };
-#if NTQ_PREFETCH
-    // L2 prefetch of the activation panel, NTQ_PREFETCH K-steps ahead of the MFMAs: one dword per 128-byte line (wave w: rows
-    // 64w + lane of the tile), into a register nothing else uses; never waited for (it is the youngest operation at every wait)
-    const bf16_t* pA_cur = p.A;
-    const bf16_t* pA_next = p.A;
-    unsigned pvo_cur = 0, pvo_next = 0;
-    auto paim = [&](int m0_, const bf16_t*& base, unsigned& vo) {
-        base = p.A + (size_t)m0_ * p.lda;
-        const int row = wave * 64 + lane, ra_max = p.M - 1 - m0_;
-        vo = (unsigned)(((row < ra_max ? row : ra_max) * p.lda) * (int)sizeof(bf16_t));
-    };
-    auto prefetch = [&](const bf16_t* base, unsigned vo) {
-        asm volatile("global_load_dword v255, %0, %1" ::"v"(vo), "s"(base) : "v255", "memory");
-    };
-#endif
-    // quarter q of the request for K-step kstep -> LDS buffer par: q = 0, 1 the activation panel (it comes from HBM), 2, 3 the
-    // weight panel (L2); 4 DMA instructions each
-    auto stage_q = [&](int kstep, int par, auto qtag) {
-        constexpr int q = decltype(qtag)::value;
-        constexpr int which = q >> 1, j0 = (q & 1) * 4;
-        const unsigned d = lds_base + (unsigned)((par * 2 + which) * LTILE * sizeof(bf16_t)) + lds_stage;
-        const bf16_t* src = (which ? sB : sA) + kstep * GBK;
-#pragma unroll
-        for (int j = j0; j < j0 + 4; ++j) glds16(src, which ? voB[j] : voA[j], d + j * 8 * GBK * (unsigned)sizeof(bf16_t));
-    };
-
-    int offA[2], offB[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int x = (((ks * 4 + lg) ^ (lr & 7)) << 3);
-        offA[ks] = (wm * 128 + lr) * GBK + x;
-        offB[ks] = (wn * 128 + lr) * GBK + x;
-    }
-    f32x4 acc[8][8];
-    bf16x8 fb0[8], fb1[8], faE[2], faO[2];
-    auto ldA2 = [&](bf16x8 (&f)[2], const bf16_t* cA, int ks, int q) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) f[t] = *reinterpret_cast<const bf16x8*>(cA + offA[ks] + (2 * q + t) * 16 * GBK);
-    };
-    auto ldB1 = [&](bf16x8& f, const bf16_t* cB, int ks, int t) { f = *reinterpret_cast<const bf16x8*>(cB + offB[ks] + t * 16 * GBK); };
-    auto mma = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[8], int q) {
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 8; ++tn)
-                acc[2 * q + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[2 * q + tm][tn], 0, 0, 0);
-    };
-    // scheduling of a phase: `mf` MFMAs then one LDS read, `n` times (the rest of the MFMAs follow)
-#define NTQ_SCHED(n, mf)                                                                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, (mf), 0);                                                                   \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                      \
-    }                                                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);
-
-    const int nk = p.K / GBK;
-    const int G = gridDim.x;
-    int v = blockIdx.x;
-    int m0, n0, nm0 = 0, nn0 = 0;
-    aim(v, m0, n0);
-    stage_q(0, 0, itag<0>{}); stage_q(0, 0, itag<1>{}); stage_q(0, 0, itag<2>{}); stage_q(0, 0, itag<3>{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    stage_q(1, 1, itag<0>{}); stage_q(1, 1, itag<1>{}); stage_q(1, 1, itag<2>{}); stage_q(1, 1, itag<3>{});
-#pragma unroll
-    for (int t = 0; t < 8; ++t) ldB1(fb0[t], lsm + LTILE, 0, t);
-    ldA2(faE, lsm, 0, 0);
-    int par = 0;
-    int pend_k = -1, pend_par = 0;      // request whose first quarter(s) have been issued
-    bool loose = false;
-
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bool has_next = v + G < p.num_tiles;
-#if NTQ_PREFETCH
-        paim(m0, pA_cur, pvo_cur);
-        if (has_next) {
-            const int tile_n = xcd_remap(v + G, p.num_tiles);
-            paim((tile_n / p.tiles_n) * LBM, pA_next, pvo_next);
-        }
-#endif
-
-        for (int kt = 0; kt < nk; ++kt) {
-            const bf16_t* cA = lsm + par * 2 * LTILE;
-            const bf16_t* cB = cA + LTILE;
-            const bf16_t* nA = lsm + (par ^ 1) * 2 * LTILE;
-            const bf16_t* nB = nA + LTILE;
-            // ---- K-slice 0
-            if (pend_k >= 0) {
-                if (NTQ_SPREAD == 2) { stage_q(pend_k, pend_par, itag<2>{}); stage_q(pend_k, pend_par, itag<3>{}); pend_k = -1; }
-                else stage_q(pend_k, pend_par, itag<1>{});
-            }
-            mma(faE, fb0, 0);
-            ldA2(faO, cA, 0, 1); ldB1(fb1[0], cB, 1, 0); ldB1(fb1[1], cB, 1, 1);
-            NTQ_SCHED(4, 4)
-            if (NTQ_SPREAD == 4 && pend_k >= 0) stage_q(pend_k, pend_par, itag<2>{});
-            mma(faO, fb0, 1);
-            ldA2(faE, cA, 0, 2); ldB1(fb1[2], cB, 1, 2); ldB1(fb1[3], cB, 1, 3);
-            NTQ_SCHED(4, 4)
-            if (NTQ_SPREAD == 4 && pend_k >= 0) { stage_q(pend_k, pend_par, itag<3>{}); pend_k = -1; }
-            mma(faE, fb0, 2);
-            ldA2(faO, cA, 0, 3); ldB1(fb1[4], cB, 1, 4); ldB1(fb1[5], cB, 1, 5);
-            NTQ_SCHED(4, 4)
-#if NTQ_PREFETCH
-            {
-                const int kp = kt + NTQ_PREFETCH;
-                if (kp < nk) prefetch(pA_cur + kp * GBK, pvo_cur);
-                else if (has_next && kp - nk < nk) prefetch(pA_next + (kp - nk) * GBK, pvo_next);
-                else prefetch(pA_cur + (nk - 1) * GBK, pvo_cur);
-            }
-#endif
-            mma(faO, fb0, 3);
-            ldA2(faE, cA, 1, 0); ldB1(fb1[6], cB, 1, 6); ldB1(fb1[7], cB, 1, 7);
-            NTQ_SCHED(4, 4)
-            // ---- K-slice 1
-            mma(faE, fb1, 0);
-            ldA2(faO, cA, 1, 1);
-            NTQ_SCHED(2, 8)
-            mma(faO, fb1, 1);
-            ldA2(faE, cA, 1, 2);
-            NTQ_SCHED(2, 8)
-            mma(faE, fb1, 2);
-            ldA2(faO, cA, 1, 3);
-            NTQ_SCHED(2, 8)
-            // every wave has read all of the current buffer; publish the next K-step, then refill the current buffer
-            if (kt == 0 && loose) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTQ_DRAIN + (NTQ_PREFETCH ? 1 : 0)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTQ_PREFETCH ? 1 : 0) : "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + 2 < nk) {
-                pend_k = kt + 2; pend_par = par;
-            } else if (has_next) {
-                if (kt + 2 == nk) aim(v + G, nm0, nn0);
-                pend_k = kt + 2 - nk; pend_par = par;
-            }
-            if (pend_k >= 0) {
-                stage_q(pend_k, pend_par, itag<0>{});
-                if (NTQ_SPREAD == 2) stage_q(pend_k, pend_par, itag<1>{});
-            }
-            mma(faO, fb1, 3);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) ldB1(fb0[t], nB, 0, t);
-            ldA2(faE, nA, 0, 0);
-            NTQ_SCHED(10, 1)
-            par ^= 1;
-        }
-
-        if (pend_k >= 0) {       // before the stores: vmcnt counts in issue order
-            if (NTQ_SPREAD == 4) stage_q(pend_k, pend_par, itag<1>{});
-            stage_q(pend_k, pend_par, itag<2>{});
-            stage_q(pend_k, pend_par, itag<3>{});
-            pend_k = -1;
-        }
-        // Epilogue: as in gemm_ntp_kernel, 16 rows x 128 columns at a time through this wave's private 8 KB of LDS (fp32, chunk
-        // XOR-swizzled by row & 7), read back as lane = (row lane/16 of a group of 4, 8 columns): 16 lanes cover 256 contiguous
-        // bytes of an output row.  Side operands are fetched by hand, 64 rows ahead.
-        constexpr bool SIDE = EPI == VITK_EPI_BIAS_RES || EPI == VITK_EPI_DGELU || EPI == VITK_EPI_MUL;
-        const int ecol = n0 + wn * 128 + (lane & 15) * 8;
-        const int erow = lane >> 4;
-        u32x4 side[SIDE ? 16 : 1];
-        auto fetch_side = [&](int tm_base) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int m = m0 + wm * 128 + (tm_base + (i >> 2)) * 16 + (i & 3) * 4 + erow;
-                m = m < p.M ? m : p.M - 1;
-                if (EPI == VITK_EPI_BIAS_RES && p.smap != nullptr) { const int c = m / p.rps; m = p.smap[c] * p.rps + (m - c * p.rps); }
-                const int n = ecol < p.N ? ecol : 0;
-                side[SIDE ? i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(nt_side_ptr<EPI>(p, m, n)));
-            }
-        };
-        if (SIDE) fetch_side(0);
-        constexpr bool BIAS = EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU && EPI != VITK_EPI_MUL;
-        float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (BIAS) add_f32<8>(p.bias + (ecol < p.N ? ecol : 0), bias8);
-#pragma unroll
-        for (int tm = 0; tm < 8; ++tm) {
-            float sv[4][8];
-            if (SIDE) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) unpack_bf16x8(side[(tm & 3) * 4 + q], sv[q]);
-                if (tm == 3) { asm volatile("" ::: "memory"); fetch_side(4); }
-            }
-#pragma unroll
-            for (int tn = 0; tn < 8; ++tn)
-                *reinterpret_cast<f32x4*>(stg + lr * 128 + (((tn * 4 + lg) ^ (lr & 7)) << 2)) = acc[tm][tn];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = q * 4 + erow;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * 128 + (((2 * (lane & 15)) ^ (r & 7)) << 2));
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * 128 + (((2 * (lane & 15) + 1) ^ (r & 7)) << 2));
-                const int m = m0 + wm * 128 + tm * 16 + r;
-                const int n = ecol;
-                if (m < p.M && n < p.N) {
-                    float rs = 1.0f;
-                    int orow = m;
-                    const float* posrow = nullptr;
-                    if (EPI == VITK_EPI_BIAS_RES) {
-                        if (p.rowscale != nullptr) rs = p.rowscale[m / p.rows_per_group];
-                        if (p.smap != nullptr) { const int c = m / p.rps; orow = p.smap[c] * p.rps + (m - c * p.rps); }
-                    }
-                    if (EPI == VITK_EPI_PATCH) {
-                        const int b = m / p.patches, pi = m - b * p.patches;
-                        orow = b * (p.patches + p.prefix) + p.prefix + pi;
-                        posrow = p.pos + (size_t)(p.prefix + pi) * p.N;
-                    }
-                    float o[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    nt_epilogue<EPI, 8>(p, o, m, n, orow, rs, posrow, SIDE ? sv[q] : nullptr, BIAS ? bias8 : nullptr);
-                }
-            }
-        }
-        if (!has_next) break;
-        loose = m0 + LBM <= p.M && n0 + LBN <= p.N;
-        v += G;
-        m0 = nm0;
-        n0 = nn0;
-    }
-#undef NTQ_SCHED
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1305,7 +1028,6 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     p.rowscale = rowscale; p.rows_per_group = rows_per_group; p.out2 = (bf16_t*)out2; p.ldout2 = ldout2;
     p.aux = (const bf16_t*)aux; p.ldaux = ldaux; p.pos = pos; p.patches = patches; p.prefix = prefix;
     p.smap = sample_map; p.rps = rows_per_sample;
-    p.stagger = 0; p.stagger_mode = 0;
     hipStream_t s = (hipStream_t)stream;
     // large problems with K a multiple of 64 take the persistent 256x256 direct-to-LDS kernel; the 128x128 register-staged kernel
     // handles K tails (zero fill) and small shapes.  VITK_GEMM_SMALL=1 forces the latter (A/B testing).
@@ -1318,29 +1040,16 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     if (big) {
         p.tiles_n = (N + LBN - 1) / LBN;
         p.num_tiles = ((M + LBM - 1) / LBM) * p.tiles_n;
-        static const bool four_waves = getenv("VITK_GEMM_NTQ") != nullptr;
-        const size_t smem = four_waves ? NTQ_LDS : NTP_LDS;
+        const size_t smem = NTP_LDS;
         const int grid = p.num_tiles < cus ? p.num_tiles : cus;      // one persistent workgroup per CU
-        {
-            static const char* sg = getenv("VITK_GEMM_STAGGER");      // percent of an estimated tile time
-            static const int pct = sg ? atoi(sg) : 0;
-            const int epi_us = (epilogue == VITK_EPI_BIAS_GELU || epilogue == VITK_EPI_BIAS_GELU_DG) ? 14
-                               : (epilogue == VITK_EPI_BIAS_RES) ? 10 : (epilogue == VITK_EPI_MUL || epilogue == VITK_EPI_DGELU) ? 6 : 3;
-            static const bool light = getenv("VITK_GEMM_STAGGER_LIGHT") != nullptr;
-            p.stagger_mode = light ? 1 : 0;
-            if (pct > 0 && p.num_tiles >= 2 * grid && (!light || p.num_tiles % grid != 0))
-                p.stagger = (int)(((K / GBK) * 1.55 + epi_us) * pct / 100.0);
-        }
 #define VITK_LAUNCH_BIG(E)                                                                                              \
     case E: {                                                                                                           \
-        static VitkLdsOnce once = {}, onceq = {};                                                                       \
-        if (int rc_ = four_waves ? vitk_lds_once(onceq, (const void*)gemm_ntq_kernel<E>, smem, "gemm_nt")               \
-                                 : vitk_lds_once(once, (const void*)gemm_ntp_kernel<E>, smem, "gemm_nt")) {             \
+        static VitkLdsOnce once = {};                                                                                   \
+        if (int rc_ = vitk_lds_once(once, (const void*)gemm_ntp_kernel<E>, smem, "gemm_nt")) {                          \
             if (pr) vitk_prof_end(stream);                                                                              \
             return rc_;                                                                                                 \
         }                                                                                                               \
-        if (four_waves) gemm_ntq_kernel<E><<<grid, 256, smem, s>>>(p);                                                  \
-        else gemm_ntp_kernel<E><<<grid, 512, smem, s>>>(p);                                                             \
+        gemm_ntp_kernel<E><<<grid, 512, smem, s>>>(p);                                                         \
     } break;
         switch (epilogue) {
             VITK_LAUNCH_BIG(VITK_EPI_PLAIN)
