@@ -39,7 +39,7 @@ enum {
     VITK_EPI_BIAS_RES = 4,   /* out_bf16 = res[m,n] + rowscale[m / rows_per_group] * (acc + bias[n])   */
     VITK_EPI_PATCH = 5,      /* out_bf16[(m/P)*(P+pre)+pre+m%P, n] = acc + bias[n] + pos[pre+m%P, n]   */
     VITK_EPI_DGELU = 6,      /* out_bf16 = acc * gelu_erf'(aux_bf16[m,n])                              */
-    VITK_EPI_BIAS_GELU_DG = 7, /* h = bf16(acc + bias[n]); out_bf16 = gelu_erf'(h); out2_bf16 = gelu_erf(h): the forward of an MLP's
+    VITK_EPI_BIAS_GELU_DG = 7, /* h = acc + bias[n] (fp32);  out_bf16 = gelu_erf'(h); out2_bf16 = gelu_erf(h): the forward of an MLP's
                                 first linear that keeps the activation's DERIVATIVE for the backward pass instead of h          */
     VITK_EPI_MUL = 8         /* out_bf16 = acc * aux_bf16[m,n]  (the backward of the above: aux = the stored derivative)       */
 };

@@ -53,8 +53,8 @@ def dgelu(x):
 
 class _GeluKeptDerivative(torch.autograd.Function):
     """exact GELU whose backward multiplies by the derivative as the HIP path keeps it between the passes: evaluated at the
-    (already bf16-rounded) pre-activation in fp32, then rounded to bf16 - one more bf16 storage point, like every other saved
-    activation"""
+    fp32 pre-activation, then rounded to bf16 - a bf16 storage point like every other saved activation (the pre-activation
+    itself is not one: nothing stores it)"""
 
     @staticmethod
     def forward(ctx, x):

@@ -149,7 +149,8 @@ class RefViT(nn.Module):
         act = lambda t: R.rnd(t, E, fwd=True, bwd=True)
         y = act(R.layernorm(x, blk.norm2.weight, blk.norm2.bias))
         tap('y2', y)
-        f1 = act(y @ w(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias)
+        # the pre-activation is never stored (the HIP path keeps gelu'(h) and gelu(h)): no forward rounding; its gradient is
+        f1 = R.rnd(y @ w(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias, E, fwd=False, bwd=True)
         tap('h', f1)
         a = R.rnd(R.gelu(f1, emulate=E), E, fwd=True, bwd=False)
         tap('a', a)

@@ -115,8 +115,8 @@ def test_forward_stagewise_identical_inputs(device, compact):
                 dropped = (sc1.reshape(B) == 0).nonzero().flatten()
                 assert torch.equal(X2[dropped], X[dropped])             # a dropped sample passes through bit for bit
             errs[f"{li}.ln2"] = rel_l2(Y2, rb(R.layernorm(X2[k2], blk.norm2.weight, blk.norm2.bias)))
-            # fc1 keeps gelu'(h) (bf16) in h's place: both outputs against the oracle's formulas on the rounded pre-activation
-            pre_act = rb(Y2 @ wq(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias)
+            # fc1 keeps gelu'(h) (bf16) in h's place: both outputs against the oracle's formulas on the fp32 pre-activation
+            pre_act = Y2 @ wq(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias
             errs[f"{li}.fc1.dgelu"] = rel_l2(Hh, rb(R.dgelu(pre_act)))
             errs[f"{li}.gelu"] = rel_l2(A, rb(R.gelu(pre_act)))
             if X3 is not None:

@@ -141,14 +141,14 @@ static __device__ __forceinline__ void nt_epilogue(const GemmNTParams& p, float 
         }
         store_bf16<W>(p.out2 + (size_t)m * p.ldout2 + n, a);
     } else if (EPI == VITK_EPI_BIAS_GELU_DG) {
-        // as BIAS_GELU, but what is kept for the backward pass is gelu'(h), rounded to bf16, in place of h
+        // what is kept for the backward pass is gelu'(h), rounded to bf16, in place of h; h itself is never stored, so both
+        // functions are evaluated on the fp32 pre-activation
         unsigned gp[W / 2];
         float a[W];
 #pragma unroll
         for (int j = 0; j < W; j += 2) {
-            const unsigned hp = pack2bf(v[j], v[j + 1]);
             float g0, g1;
-            gelu_dgelu_erf2(__uint_as_float(hp << 16), __uint_as_float(hp & 0xffff0000u), a[j], a[j + 1], g0, g1);
+            gelu_dgelu_erf2(v[j], v[j + 1], a[j], a[j + 1], g0, g1);
             gp[j / 2] = pack2bf(g0, g1);
         }
         bf16_t* cp = (bf16_t*)p.C + (size_t)m * p.ldc + n;
