@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--model", default="vit_base_patch16_224")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--prof-every", type=int, default=5, help="bracket the kernel launches of every n-th timed step with HIP events")
+    ap.add_argument("--prof-every", type=int, default=10, help="bracket the kernel launches of every n-th timed step with HIP events")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
