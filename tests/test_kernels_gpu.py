@@ -148,6 +148,28 @@ def test_gemm_nt_epilogues(device, M, N, K):
     assert rel_l2(resd.float(), rb(res.float() + acc)) <= REL_TOL
 
 
+def test_gemm_nt_concurrent_streams(device):
+    """The persistent kernel deals its tiles through per-stream counters that it leaves zeroed: launches that overlap on two streams,
+    and repeated launches on one, give bit for bit what a lone launch gives"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    a1, b1 = _randb((4096, 768), g).to(device), _randb((768, 768), g, 0.05).to(device)
+    a2, b2 = _randb((3000, 256), g).to(device), _randb((1024, 256), g, 0.05).to(device)
+    want1, want2 = ops.gemm_nt(a1, b1), ops.gemm_nt(a2, b2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(6):
+        with torch.cuda.stream(s1):
+            o1 = ops.gemm_nt(a1, b1)
+        with torch.cuda.stream(s2):
+            o2 = ops.gemm_nt(a2, b2)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert torch.equal(o1, want1) and torch.equal(o2, want2)
+
+
 def test_gemm_nt_patch_epilogue(device):
     from vision_transformers_torch_xla_amd import _lib
     ops = _ops()

@@ -18,6 +18,9 @@ SOURCES = ["api.hip", "layernorm.hip", "gemm.hip", "attention.hip", "elementwise
 HEADERS = [CSRC / "common.h", CSRC.parent.parent / "include" / "vitk.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-inline-asm", "-Wno-cuda-compat", "-Wno-pass-failed"]
+# gemm.hip: the tile claim of the persistent kernel is ONE lane's atomic whose result is used a whole tile later; hipcc's atomic
+# optimizer would turn it into a wave-wide reduction and wait for the result on the spot
+EXTRA_FLAGS = {"gemm.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 
 
 def _hipcc() -> str:
@@ -48,7 +51,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc, *FLAGS, "-c", str(s), "-o", str(o)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s.name, []), "-c", str(s), "-o", str(o)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

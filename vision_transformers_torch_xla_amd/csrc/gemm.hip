@@ -6,8 +6,8 @@
 // Each has two kernels.
 //   gemm_ntp_kernel / gemm_tnb_kernel: the large-tile kernels every big linear takes - one 512-thread workgroup per compute
 //     unit, 256 x 256 tiles, 8 waves of 128 x 64 (128 accumulator registers), operands global -> LDS by LDS-DMA into a
-//     double-buffered 128 KB image, fragments read one 16-MFMA phase ahead.  gemm_ntp is persistent (a workgroup walks its
-//     tiles, the K-steps of all of them one continuous request stream) and transposes its accumulators through LDS so that
+//     double-buffered 128 KB image, fragments read one 16-MFMA phase ahead.  gemm_ntp is persistent (a workgroup claims tile
+//     after tile, the K-steps of all of them one continuous request stream) and transposes its accumulators through LDS so that
 //     every global access of the epilogue is a full line; gemm_tnb runs one (tile, row range) task per workgroup and leaves
 //     fp32 partial tiles for a fixed-order reduction.  Details at each kernel.
 //   gemm_nt_kernel / gemm_tn_kernel: 128 x 128 tiles, 4 waves, operands staged through registers; they take what the large
@@ -18,6 +18,7 @@
 // 4 consecutive output columns of one row.
 #include "common.h"
 #include <cstdlib>
+#include <mutex>
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <int V> struct itag { static constexpr int value = V; };
@@ -42,6 +43,7 @@ struct GemmNTParams {
     const float* pos; int patches; int prefix;
     int tiles_n; int num_tiles;
     const int* smap; int rps;     // BIAS_RES only: output / residual row of GEMM row m is smap[m / rps] * rps + m % rps
+    unsigned* sched;              // persistent kernel: this launch's tile counters, [8] per XCD + [8] = workgroups that have left
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Remap so that every XCD works on a
@@ -399,8 +401,21 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
 
     const int nk = p.K / GBK;
     const int G = gridDim.x;
-    int v = blockIdx.x;
+    // Tiles are dealt dynamically: a workgroup's first tile is its block index, every further one is claimed from its XCD's
+    // counter (claim c of XCD x is tile index G + 8 c + x, so an XCD keeps its contiguous share of the tile order).  A workgroup
+    // that reaches its compute unit late - another stream's kernel or a collective was holding it - finds the tiles already taken by
+    // the others instead of delaying the launch by its whole static share.  The claim for the tile after next leaves one tile
+    // ahead (wave 0, before the epilogue's stores) and reaches the other waves through LDS at the next tile's first barrier.
+    const int xcd = blockIdx.x & 7;
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    lds_u32* mailbox = (lds_u32*)(__UINTPTR_TYPE__)(lds_base + (unsigned)(4 * LTILE * sizeof(bf16_t)));   // first word of wave 0's epilogue staging
+    unsigned claim = 0;
+    auto issue_claim = [&]() {
+        if (wave == 0 && lane == 0) claim = atomicAdd(&p.sched[xcd], 1u);
+    };
+    int v = blockIdx.x, vn = 0;
     int m0, n0, nm0 = 0, nn0 = 0;
+    issue_claim();
     aim(v, m0, n0);
     stageA(0, 0);
     stageB(0, 0);
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bool has_next = v + G < p.num_tiles;
+        bool has_next = false;       // known from the first barrier of the tile on
 
         for (int kt = 0; kt < nk; ++kt) {
             const bf16_t* cA = lsm + par * 2 * LTILE;
@@ -454,13 +469,21 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
             // so in a tile's first step the previous tile's output stores (all younger than the request) may stay pending.
             if (kt == 0 && loose) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTP_DRAIN) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (kt == 0) {
+                if (wave == 0 && lane == 0) *mailbox = (unsigned)G + 8u * claim + (unsigned)xcd;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (kt == 0) {
+                vn = __builtin_amdgcn_readfirstlane((int)*mailbox);
+                has_next = (unsigned)vn < (unsigned)p.num_tiles;
+            }
             if (kt + 2 < nk) {
                 stageA(kt + 2, par);
                 pend_k = kt + 2; pend_par = par;
             } else if (has_next) {
-                if (kt + 2 == nk) aim(v + G, nm0, nn0);
+                if (kt + 2 == nk) aim(vn, nm0, nn0);
                 stageA(kt + 2 - nk, par);
                 pend_k = kt + 2 - nk; pend_par = par;
             }
@@ -475,6 +498,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         }
 
         if (pend_k >= 0) { stageB(pend_k, pend_par); pend_k = -1; }      // before the stores: vmcnt counts in issue order
+        if (has_next) issue_claim();                                      // likewise: the claim is older than every store
         // Epilogue.  The MFMA layout (lane = row lr, 4 columns) would store 32-byte pieces of 16 rows per instruction, and
         // the store path is paid per lane-access, not per byte.  Transpose through this wave's private 4 KB of LDS instead
         // (fp32, so the arithmetic is unchanged): 16 rows x 64 columns at a time, read back as lane = (row lane/8, 8
@@ -538,9 +562,17 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         }
         if (!has_next) break;
         loose = m0 + LBM <= p.M && n0 + LBN <= p.N;      // a full tile: every lane stored all 16 pieces
-        v += G;
+        v = vn;
         m0 = nm0;
         n0 = nn0;
+    }
+    // the last workgroup to leave zeroes the counters for the next launch that uses them
+    if (wave == 0 && lane == 0) {
+        const unsigned left = atomicAdd(&p.sched[8], 1u);
+        if (left == (unsigned)G - 1u) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) p.sched[i] = 0u;
+        }
     }
 }
 
@@ -979,6 +1011,42 @@ static TnPlan tn_plan(int M, int N, int K) {
     return q;
 }
 
+// Tile counters of the persistent NT kernel: one set of 16 words per (device, stream) - launches of one stream run one after the
+// other and the kernel leaves its set zeroed, launches of different streams may overlap and must not share one.  In host code the
+// array's name is only a stand-in: its device address comes from hipGetSymbolAddress, once per device.
+#define NTP_SCHED_SLOTS 256
+static __device__ __align__(256) unsigned ntp_sched[NTP_SCHED_SLOTS * 16];
+struct NtpSchedDev { unsigned* base = nullptr; int used = 0; void* streams[NTP_SCHED_SLOTS]; };
+static std::mutex g_ntp_sched_mu;
+static NtpSchedDev g_ntp_sched[64];
+
+static unsigned* ntp_sched_slot(void* stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        vitk_set_error("gemm_nt: cannot query the current device");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_ntp_sched_mu);
+    NtpSchedDev& d = g_ntp_sched[dev];
+    if (d.base == nullptr) {
+        unsigned* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(ntp_sched));
+        if (e != hipSuccess || ptr == nullptr) {
+            vitk_set_error("gemm_nt: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return nullptr;
+        }
+        d.base = ptr;
+    }
+    for (int i = 0; i < d.used; ++i)
+        if (d.streams[i] == stream) return d.base + (size_t)i * 16;
+    if (d.used == NTP_SCHED_SLOTS) {
+        vitk_set_error("gemm_nt: more than %d streams have launched GEMMs on device %d", NTP_SCHED_SLOTS, dev);
+        return nullptr;
+    }
+    d.streams[d.used] = stream;
+    return d.base + (size_t)(d.used++) * 16;
+}
+
 // compute units of the current device (cached per device id); <= 0 on failure
 static int vitk_num_cus() {
     static int cache[64] = {0};
@@ -1036,6 +1104,11 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     const bool big = !force_small && K % GBK == 0 && K >= 2 * GBK && M >= 512 && N >= 128 && N % 8 == 0 && ld8;
     const int cus = big ? vitk_num_cus() : 1;
     if (cus <= 0) { vitk_set_error("gemm_nt: cannot query the compute-unit count"); return VITK_ELAUNCH; }
+    p.sched = nullptr;
+    if (big) {
+        p.sched = ntp_sched_slot(stream);
+        if (p.sched == nullptr) return VITK_ELAUNCH;
+    }
     const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_NT);       // every return below closes the bracket
     if (big) {
         p.tiles_n = (N + LBN - 1) / LBN;
