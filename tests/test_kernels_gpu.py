@@ -170,6 +170,26 @@ def test_gemm_nt_concurrent_streams(device):
         assert torch.equal(o1, want1) and torch.equal(o2, want2)
 
 
+def test_gemm_nt_shape_sweep(device):
+    """Persistent-kernel shapes chosen at random (seeded): ragged M and N, tile counts below, around and far above the
+    compute-unit count (so some workgroups claim no second tile, some many), K from two steps up; plain and residual epilogues"""
+    from vision_transformers_torch_xla_amd import _lib
+    ops = _ops()
+    rng = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    shapes = [(512, 128, 128), (513, 136, 192), (256 * 17 + 3, 264, 128), (256 * 40, 256 * 7, 128), (256 * 33 + 100, 1000, 320)]
+    shapes += [(ri(512, 9000), 8 * ri(16, 160), 64 * ri(2, 9)) for _ in range(14)]
+    for (M, N, K) in shapes:
+        a, b = _randb((M, K), rng).to(device), _randb((N, K), rng, 0.05).to(device)
+        want = rb(a.float().cpu().double() @ b.float().cpu().double().t())
+        got = ops.gemm_nt(a, b)
+        assert rel_l2(got.float(), want) <= REL_TOL, (M, N, K)
+        assert bf16_excess(got.float().cpu(), (a.float().cpu().double() @ b.float().cpu().double().t()).float(), atol=1e-4) <= 1, (M, N, K)
+        res = _randb((M, N), rng).to(device)
+        got = ops.gemm_nt(a, b, epilogue=_lib.EPI_BIAS_RES, bias=torch.zeros(N, device=device), res=res)
+        assert rel_l2(got.float(), rb(res.float().cpu().double() + a.float().cpu().double() @ b.float().cpu().double().t())) <= REL_TOL, (M, N, K)
+
+
 def test_gemm_nt_patch_epilogue(device):
     from vision_transformers_torch_xla_amd import _lib
     ops = _ops()
