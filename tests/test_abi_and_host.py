@@ -88,7 +88,8 @@ def test_create_model_registry_and_errors():
     with pytest.raises(VitkError, match="head dim"):
         create_model("vit_tiny_patch16_224", embed_dim=200, num_heads=4, depth=1)               # 50: not a multiple of 8
     with pytest.raises(VitkError, match="tokens exceed"):
-        create_model("my_vit_mini", img_size=384, depth=1)                                       # 577 tokens need head dim 64
+        create_model("my_vit_xs", img_size=384, depth=1)                                         # 577 tokens need head dim <= 64
+    assert create_model("my_vit_mini", img_size=384, depth=1)._pad_heads                          # 48 runs zero-padded to 64
     with pytest.raises(VitkError):
         m(torch.zeros(1, 3, 224, 224))                                                            # CPU input: no fallback
     assert m.no_weight_decay() == {"pos_embed", "cls_token", "dist_token"}

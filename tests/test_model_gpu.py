@@ -272,6 +272,32 @@ def test_other_head_dim_models(device, name):
     assert rel_l2(gv, rv) <= E2E_GRAD_TOL
 
 
+def test_padded_heads_match_the_unpadded_kernels(device):
+    """head dim 48 zero-padded to the 64-wide MFMA attention kernels against the same model on the vector-arithmetic kernels of
+    its own head dim: logits and every gradient agree to bf16 accuracy; parameters keep timm's shapes; a second backward
+    accumulates, zero_grad makes the next one overwrite"""
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    ref, m = _pair("my_vit_mini", device, depth=2, global_pool="avg", dpr=0.0)
+    assert m._pad_heads and m.head_dim == 48
+    assert tuple(m.blocks[0].attn.qkv.weight.shape) == (432, 144) and tuple(m.blocks[0].attn.proj.weight.shape) == (144, 144)
+    crit = LabelSmoothingCrossEntropy(0.1)
+    x, y = _batch(4, 224, 40, 23)
+    m.train(); m.zero_grad()
+    out_p = m(x.to(device)); crit(out_p, y.to(device)).backward()
+    g_p = m._flat["g"].clone()
+    crit(m(x.to(device)), y.to(device)).backward()
+    assert rel_l2(m._flat["g"], 2 * g_p) <= 1e-6
+    m.zero_grad()
+    crit(m(x.to(device)), y.to(device)).backward()
+    assert torch.equal(m._flat["g"], g_p)
+    m._pad_heads = False                                   # the same weights through the head-dim-48 kernels
+    m._flatten(device)
+    m.zero_grad()
+    out_g = m(x.to(device)); crit(out_g, y.to(device)).backward()
+    print(f"padded vs unpadded: logits {rel_l2(out_p, out_g):.2e}, gradient {rel_l2(g_p, m._flat['g']):.2e}")
+    assert rel_l2(out_p, out_g) <= E2E_TOL and rel_l2(g_p, m._flat["g"]) <= E2E_GRAD_TOL
+
+
 def test_grad_accumulation_and_zero_grad(device):
     ref, m = _pair("vit_tiny_patch16_224", device, depth=2)
     x, y = _batch(4, 224, 40, 11)

@@ -240,9 +240,13 @@ class VisionTransformer(nn.Module):
         self.num_patches = self.patch_embed.num_patches
         self.num_tokens = self.num_patches + self.num_prefix_tokens
         self.head_dim = embed_dim // num_heads
-        # head dim 64 runs on the MFMA attention kernels (up to 608 tokens); the other head dims of the reference's size table
-        # (48, 72: models/my_vit.py:84-165) on the vector-arithmetic kernels (up to 256 tokens)
-        limit = 608 if self.head_dim == 64 else 256
+        # Head dim 64 runs on the MFMA attention kernels (up to 608 tokens).  A smaller head dim (48: my_vit_mini,
+        # models/my_vit.py:84-93) runs on them too, ZERO-PADDED to 64: the qkv and proj GEMMs read bf16 weight copies with 64 rows /
+        # columns per head, the padding rows, columns and bias entries zero, so the padding lanes of q, k, v, the attention output
+        # and every gradient that flows through them are exactly zero and no result changes; parameters, gradients and state dicts
+        # keep timm's shapes.  Larger head dims (72: my_vit_xs) take the vector-arithmetic kernels (up to 256 tokens).
+        self._pad_heads = self.head_dim < 64
+        limit = 608 if self.head_dim <= 64 else 256
         if self.num_tokens > limit:
             raise VitkError(f"{self.num_tokens} tokens exceed the attention kernels' limit for head dim {self.head_dim} ({limit})")
         # registration order = timm's named_parameters() order (cls_token, pos_embed, dist_token: models/deit.py:41-43 adds the
@@ -350,6 +354,7 @@ class VisionTransformer(nn.Module):
         # transposed weight copies and their descriptor table belong to THIS bf16 buffer: a table kept across a re-flatten
         # would name freed memory if the allocator ever handed the old address out again
         self._wt = {}
+        self._wpad = {}
         self._wt_plan = None
         self._wt_plan_key = None
         self._weights_version = None
@@ -444,16 +449,33 @@ class VisionTransformer(nn.Module):
     def _refresh_transposes(self):
         """[in, out] bf16 copies of the linears: the data-gradient GEMM dX = dY @ W runs as gemm_nt(dY, W^T)."""
         key = (self._flat["b"].data_ptr(), str(self._flat["b"].device))
+        H, hd = self.num_heads, self.head_dim
         if getattr(self, "_wt_plan_key", None) != key:
             pairs = []
+            self._wpad = {}
             for n, src in self._wb.items():
                 if n == "patch_embed.proj.weight":      # the image needs no gradient
                     continue
+                if self._pad_heads and n.endswith("attn.qkv.weight"):        # [3 H hd, D] -> [3 H 64, D], zero rows between
+                    src = self._wpad[n] = torch.zeros((3 * H * 64, src.shape[1]), dtype=bf16, device=src.device)
+                    self._wpad[n[:-6] + "bias"] = torch.zeros(3 * H * 64, dtype=f32, device=src.device)
+                elif self._pad_heads and n.endswith("attn.proj.weight"):     # [D, H hd] -> [D, H 64], zero columns between
+                    src = self._wpad[n] = torch.zeros((src.shape[0], H * 64), dtype=bf16, device=src.device)
                 dst = torch.empty((src.shape[1], src.shape[0]), dtype=bf16, device=src.device)
                 self._wt[n] = dst
                 pairs.append((src, dst))
             self._wt_plan = ops.transpose_plan(pairs)   # one launch for all of them
             self._wt_plan_key = key
+        if self._pad_heads:
+            # refresh the padded copies (strided device copies of a few hundred KB; torch's copy kernels)
+            named = dict(zip(self._pnames, self._plist))
+            for n, dst in self._wpad.items():
+                if n.endswith("qkv.weight"):
+                    dst.view(3 * H, 64, -1)[:, :hd].copy_(self._wb[n].view(3 * H, hd, -1))
+                elif n.endswith("qkv.bias"):
+                    dst.view(3 * H, 64)[:, :hd].copy_(named[n].detach().view(3 * H, hd))
+                else:
+                    dst.view(-1, H, 64)[:, :, :hd].copy_(self._wb[n].view(-1, H, hd))
         ops.transpose_bf16_batched(self._wt_plan)
 
     def _views_ok(self):
@@ -507,6 +529,7 @@ class VisionTransformer(nn.Module):
         N, D, H, npre, P = self.num_tokens, self.embed_dim, self.num_heads, self.num_prefix_tokens, self.num_patches
         M = B * N
         wb = self._wb
+        wa = self._wpad if self._pad_heads else wb      # qkv / proj weights as the attention branch reads them
         scale = self.head_dim ** -0.5
         patches = ops.im2col_patches(img, self.patch_size)
         x = torch.empty((M, D), dtype=bf16, device=img.device)
@@ -526,15 +549,16 @@ class VisionTransformer(nn.Module):
                 nb = s1.nk if c1 else B
                 y1, m1, r1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, smap=s1.kept if c1 else None,
                                                rows_per_sample=N)
-                qkv = ops.gemm_nt(y1, wb[pre + "attn.qkv.weight"], epilogue=EPI_BIAS, bias=blk.attn.qkv.bias)
+                wq, bq, wp = wa[pre + "attn.qkv.weight"], (wa[pre + "attn.qkv.bias"] if self._pad_heads else blk.attn.qkv.bias), wa[pre + "attn.proj.weight"]
+                qkv = ops.gemm_nt(y1, wq, epilogue=EPI_BIAS, bias=bq)
                 o, lse = ops.attention_fwd(qkv, nb, N, H, scale)
                 if c1:
                     x2 = torch.empty_like(x)
-                    ops.gemm_nt(o, wb[pre + "attn.proj.weight"], epilogue=EPI_BIAS_RES, bias=blk.attn.proj.bias, res=x, rowscale=s1.scale_c,
+                    ops.gemm_nt(o, wp, epilogue=EPI_BIAS_RES, bias=blk.attn.proj.bias, res=x, rowscale=s1.scale_c,
                                 rows_per_group=N, out=x2, smap=s1.kept, rows_per_sample=N)
                     ops.copy_samples(x, x2, s1.dropped, N * D)
                 else:
-                    x2 = ops.gemm_nt(o, wb[pre + "attn.proj.weight"], epilogue=EPI_BIAS_RES, bias=blk.attn.proj.bias, res=x,
+                    x2 = ops.gemm_nt(o, wp, epilogue=EPI_BIAS_RES, bias=blk.attn.proj.bias, res=x,
                                      rowscale=None if s1 is None else s1.scale, rows_per_group=N)
             # ---- MLP branch: x3 = x2 + s2 * fc2(gelu(fc1(ln2(x2))))
             if s2 is not None and s2.compact and s2.nk == 0:
@@ -705,15 +729,36 @@ class VisionTransformer(nn.Module):
         side = self._wgrad_stream()
         held, lagging = [], None        # operands of the current block; (event, operands) of the block before
 
+        Hh, hd = self.num_heads, self.head_dim
+
+        def wgrad_gemm(dy, xin, wname, bname, ws_):
+            """dW (+)= dy^T xin, dbias (+)= column sums of dy, into the flat gradient buffer.  With zero-padded heads the qkv / proj
+            products come out in the padded shape: the real rows / columns are copied (or added) across afterwards."""
+            if self._pad_heads and wname.endswith("attn.qkv.weight"):
+                tw = torch.empty((3 * Hh * 64, xin.shape[1]), dtype=f32, device=dy.device)
+                tb = torch.empty(3 * Hh * 64, dtype=f32, device=dy.device)
+                ops.gemm_tn(dy, xin, tw, dbias=tb, accumulate=False, ws=ws_)
+                gw, gb = g[wname].view(3 * Hh, hd, -1), g[bname].view(3 * Hh, hd)
+                sw, sb = tw.view(3 * Hh, 64, -1)[:, :hd], tb.view(3 * Hh, 64)[:, :hd]
+                (gw.add_(sw), gb.add_(sb)) if acc else (gw.copy_(sw), gb.copy_(sb))
+            elif self._pad_heads and wname.endswith("attn.proj.weight"):
+                tw = torch.empty((dy.shape[1], Hh * 64), dtype=f32, device=dy.device)
+                tb = torch.empty(dy.shape[1], dtype=f32, device=dy.device)
+                ops.gemm_tn(dy, xin, tw, dbias=tb, accumulate=False, ws=ws_)
+                gw, sw = g[wname].view(-1, Hh, hd), tw.view(-1, Hh, 64)[:, :, :hd]
+                (gw.add_(sw), g[bname].add_(tb)) if acc else (gw.copy_(sw), g[bname].copy_(tb))
+            else:
+                ops.gemm_tn(dy, xin, g[wname], dbias=g[bname], accumulate=acc, ws=ws_)
+
         def wgrad(dy, xin, wname, bname):
             if side is None:
-                ops.gemm_tn(dy, xin, g[wname], dbias=g[bname], accumulate=acc, ws=ws)
+                wgrad_gemm(dy, xin, wname, bname, ws)
                 return
             ev = torch.cuda.Event()
             ev.record()
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                ops.gemm_tn(dy, xin, g[wname], dbias=g[bname], accumulate=acc, ws=self._ws_side)
+                wgrad_gemm(dy, xin, wname, bname, self._ws_side)
             held.append((dy, xin))
 
         def side_event():
