@@ -142,8 +142,10 @@ size_t vitk_attention_bwd_workspace(int B, int N, int H);
 int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                        int B, int N, int H, float scale, void* workspace, size_t workspace_bytes, void* stream);
 /* The same for head dims other than 64 - a multiple of 8 up to 96 (48 and 72: my_vit_mini / my_vit_xs, models/my_vit.py:84-165) -
- * and up to 256 tokens: qkv [B*N, 3*H*head_dim], out / dout [B*N, H*head_dim], dqkv like qkv, lse [B, H, N].  Vector arithmetic
- * (one thread per row) with the bf16 storage points of the 64-wide kernels; no workspace. */
+ * and up to 256 tokens: qkv [B*N, 3*H*head_dim], out / dout [B*N, H*head_dim], dqkv like qkv, lse [B, H, N]; no workspace.
+ * head_dim 96 up to 224 tokens runs on the MFMA kernels (256-byte LDS rows, one workgroup per compute unit); everything else on
+ * vector arithmetic (one thread per row) with the bf16 storage points of the MFMA kernels.  (The Python model pads heads of
+ * 48 / 72 columns with zeros to 64 / 96 and so reaches the MFMA kernels for every size of the reference's table.) */
 int vitk_attention_generic_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int head_dim, float scale, void* stream);
 int vitk_attention_generic_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N, int H,
                                int head_dim, float scale, void* stream);

@@ -314,7 +314,8 @@ def test_label_out_of_range_gives_nan_not_a_wild_read(device):
     assert torch.isfinite(CrossEntropyLoss()(z.to(device), good.to(device))).item()
 
 
-@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 48), (2, 197, 4, 72), (1, 256, 1, 96), (3, 50, 2, 8), (1, 1, 1, 40), (1, 198, 2, 80)])
+@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 3, 48), (2, 197, 4, 72), (1, 256, 1, 96), (3, 50, 2, 8), (1, 1, 1, 40), (1, 198, 2, 80),
+                                      (2, 197, 4, 96), (3, 224, 2, 96), (2, 33, 3, 96), (1, 1, 1, 96), (2, 130, 5, 96)])   # 96 <= 224 tokens: MFMA
 def test_attention_other_head_dims(device, B, N, H, hd):
     """head dims other than 64 (48 and 72 are my_vit_mini / my_vit_xs): the vector-arithmetic kernels against the oracle with the
     same bf16 storage points, forward and backward (backward fed the kernel's own O and log-sum-exp), and against exact math"""

@@ -272,14 +272,16 @@ def test_other_head_dim_models(device, name):
     assert rel_l2(gv, rv) <= E2E_GRAD_TOL
 
 
-def test_padded_heads_match_the_unpadded_kernels(device):
-    """head dim 48 zero-padded to the 64-wide MFMA attention kernels against the same model on the vector-arithmetic kernels of
-    its own head dim: logits and every gradient agree to bf16 accuracy; parameters keep timm's shapes; a second backward
-    accumulates, zero_grad makes the next one overwrite"""
+@pytest.mark.parametrize("name,hd,hp", [("my_vit_mini", 48, 64), ("my_vit_xs", 72, 96)])
+def test_padded_heads_match_the_unpadded_kernels(device, name, hd, hp):
+    """head dims 48 / 72 zero-padded to the 64- / 96-wide MFMA attention kernels against the same model on the vector-arithmetic
+    kernels of its own head dim: logits and every gradient agree to bf16 accuracy; parameters keep timm's shapes; a second
+    backward accumulates, zero_grad makes the next one overwrite"""
     from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
-    ref, m = _pair("my_vit_mini", device, depth=2, global_pool="avg", dpr=0.0)
-    assert m._pad_heads and m.head_dim == 48
-    assert tuple(m.blocks[0].attn.qkv.weight.shape) == (432, 144) and tuple(m.blocks[0].attn.proj.weight.shape) == (144, 144)
+    ref, m = _pair(name, device, depth=2, global_pool="avg", dpr=0.0)
+    assert m._pad_heads and m.head_dim == hd and m._hd_pad == hp
+    D = m.embed_dim
+    assert tuple(m.blocks[0].attn.qkv.weight.shape) == (3 * D, D) and tuple(m.blocks[0].attn.proj.weight.shape) == (D, D)
     crit = LabelSmoothingCrossEntropy(0.1)
     x, y = _batch(4, 224, 40, 23)
     m.train(); m.zero_grad()
@@ -290,7 +292,7 @@ def test_padded_heads_match_the_unpadded_kernels(device):
     m.zero_grad()
     crit(m(x.to(device)), y.to(device)).backward()
     assert torch.equal(m._flat["g"], g_p)
-    m._pad_heads = False                                   # the same weights through the head-dim-48 kernels
+    m._pad_heads, m._hd_pad = False, hd                    # the same weights through the kernels of the head dim itself
     m._flatten(device)
     m.zero_grad()
     out_g = m(x.to(device)); crit(out_g, y.to(device)).backward()

@@ -1,4 +1,5 @@
-// Fused multi-head self-attention (head dim 64, no mask, no dropout) forward and backward for gfx950.
+// Fused multi-head self-attention (head dims 64 and 96 on MFMA, others up to 96 on vector arithmetic; no mask, no dropout) forward
+// and backward for gfx950.
 //
 // Token counts are small (197 / 198 / 577), so one workgroup owns a whole (batch, head): K and V of the head
 // are staged once into LDS (<= 608 keys), and the softmax over all keys of a 16-query tile is done in
@@ -8,7 +9,7 @@
 //             V^T fragments by the transposing LDS read ds_read_b64_tr_b16.
 //   backward: two phases over one LDS image (Q, dO first; then K, V): key-owner waves form dK, dV, query-owner waves
 //             recompute the scores and form dQ; nothing crosses between waves (see attn_bwd_res_kernel).
-// qkv is nn.Linear(D,3D)'s output [B*N, 3*H*64]; column = which*H*64 + head*64 + d.
+// qkv is nn.Linear(D,3D)'s output [B*N, 3*H*hd]; column = which*H*hd + head*hd + d (hd = 64, or 96: AttnGeo below).
 #include "common.h"
 
 bool vitk_prof_begin(void* stream, double flop, int kind);
@@ -35,6 +36,18 @@ static __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 static __device__ __forceinline__ int swz(int row, int col) {
     return row * HD + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7));
 }
+// Geometry of the MFMA kernels for a head of HDP columns in memory (a multiple of 32): 64, or 96 for the heads between 64 and 96
+// wide, which the model pads with zeros (my_vit_xs: 72).  LDS rows are HDW elements: 64 (128 B; chunk index XOR row & 7, rows
+// alternate between the two halves of the banks) or 128 (256 B: every row starts at bank 0, so the chunk index is XOR-ed with
+// 2 * (row & 7), which keeps the 16-lane groups of ds_read_b128 and the 8 rows x 32 B of a transposing read on distinct banks).
+// A 1 KB DMA piece covers RPP rows.
+template <int HDP>
+struct AttnGeo {
+    static constexpr int HDW = HDP == 64 ? 64 : 128;
+    static constexpr int NKS = HDP / 32, NDT = HDP / 16, NCH = HDP / 8, CPR = HDW / 8, RPP = 512 / HDW;
+    static __device__ __forceinline__ int sig(int row) { return HDW == 64 ? (row & 7) : ((row & 7) << 1); }
+    static __device__ __forceinline__ int swz(int row, int col) { return row * HDW + ((((col >> 3) ^ sig(row)) << 3) | (col & 7)); }
+};
 
 // Output rows.  After the transposed products a lane holds, for row lr of a 16-row tile, four 8-byte pieces: 4 consecutive bf16
 // at column 16*dt + 4*lg.  Stores cost per instruction, not per byte, so pieces are paired first: two exchanges between
@@ -57,29 +70,33 @@ static __device__ __forceinline__ int pair_col(int dtA, int dtB, int lg) { retur
 // padding (C = -inf + finite stays -inf), which is the whole masking cost.
 // WAVES waves per workgroup and WPE waves per SIMD asked of the compiler: 7 and 4 up to 224 keys (13 query tiles at 197
 // tokens = at most 2 per wave; two workgroups per CU), 4 and 1 beyond.
-template <int MAXT, int WAVES, int WPE>
+template <int MAXT, int WAVES, int WPE, int HDP = 64>
 __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                    float* __restrict__ lse, int N, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+    using G = AttnGeo<HDP>;
+    constexpr int HDW = G::HDW, NKS = G::NKS, NDT = G::NDT, NCH = G::NCH, CPR = G::CPR, RPP = G::RPP;
     constexpr int NPAD = MAXT * 16;
     bf16_t* Ks = reinterpret_cast<bf16_t*>(attn_smem);
-    bf16_t* Vs = Ks + NPAD * HD;
+    bf16_t* Vs = Ks + NPAD * HDW;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4, lq = lr >> 2, lp = lr & 3;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int D = H * HD, ld = 3 * D;
-    const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
+    const int D = H * HDP, ld = 3 * D;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * HDP;
 
-    {   // DMA fill: a piece = 8 rows x 128 B; pieces [0, NPAD/8) are K, the rest V
+    {   // DMA fill: a piece = RPP rows x (HDW * 2) B; pieces [0, NPAD/RPP) are K, the rest V
         const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(Ks));
-        const int prow = lane >> 3, ppos = lane & 7;
-        for (int pc = wave; pc < 2 * (NPAD / 8); pc += WAVES) {
-            const int which = pc >= NPAD / 8 ? 1 : 0;
-            const int row = (pc - which * (NPAD / 8)) * 8 + prow;
+        const int prow = lane / CPR, ppos = lane % CPR;
+        for (int pc = wave; pc < 2 * (NPAD / RPP); pc += WAVES) {
+            const int which = pc >= NPAD / RPP ? 1 : 0;
+            const int row = (pc - which * (NPAD / RPP)) * RPP + prow;
             const int srow = row < N ? row : N - 1;
-            const bf16_t* src = base + (size_t)srow * ld + (1 + which) * D + ((ppos ^ (row & 7)) << 3);
+            int ch = ppos ^ G::sig(row);
+            if (CPR > NCH && ch >= NCH) ch -= 8;          // slots past the head's columns: any valid chunk, never read
+            const bf16_t* src = base + (size_t)srow * ld + (1 + which) * D + (ch << 3);
             glds16_v(src, lds0 + (unsigned)pc * 1024u);
         }
     }
@@ -91,19 +108,21 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) tail0[i][r] = ((MAXT - 2 + i) * 16 + 4 * lg + r < N) ? 0.f : -INFINITY;
-    const int koff0 = lr * HD + ((lg ^ (lr & 7)) << 3), koff1 = lr * HD + (((4 + lg) ^ (lr & 7)) << 3);   // (16t + lr) & 7 == lr & 7
-    int voff[4];        // (32u + 4lg + lq) & 7 == (4lg + lq) & 7, and the same 16 rows further: one offset per d tile serves all u
+    int koff[NKS];      // b128 fragment of row 16t + lr, K-slice s; (16t + lr) & 7 == lr & 7
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) voff[dt] = swz(4 * lg + lq, dt * 16 + 4 * lp);
+    for (int ks = 0; ks < NKS; ++ks) koff[ks] = lr * HDW + (((4 * ks + lg) ^ G::sig(lr)) << 3);
+    int voff[NDT];      // (32u + 4lg + lq) & 7 == (4lg + lq) & 7, and the same 16 rows further: one offset per d tile serves all u
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) voff[dt] = G::swz(4 * lg + lq, dt * 16 + 4 * lp);
 
-    auto load_q = [&](int qt, bf16x8 (&qf)[2]) {
+    auto load_q = [&](int qt, bf16x8 (&qf)[NKS]) {
         int q = qt * 16 + lr;
         q = q < N ? q : N - 1;
         const bf16_t* qp = base + (size_t)q * ld + 8 * lg;
-        qf[0] = *reinterpret_cast<const bf16x8*>(qp);
-        qf[1] = *reinterpret_cast<const bf16x8*>(qp + 32);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
     };
-    bf16x8 qf[2], qn[2];
+    bf16x8 qf[NKS], qn[NKS];
     if (wave < nqt) load_q(wave, qf);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -113,18 +132,21 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
         // K fragments are fetched one key tile ahead by hand and the scheduler is fenced per tile: left alone, hipcc hoists every
         // fragment load of the unrolled loop to the top and spills
         f32x4 s[MAXT];
-        bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(&Ks[koff0]);
-        bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(&Ks[koff1]);
+        bf16x8 kf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(&Ks[koff[ks]]);
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            const bf16x8 a0 = kf0, a1 = kf1;
+            bf16x8 a[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) a[ks] = kf[ks];
             if (t + 1 < MAXT) {
-                kf0 = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HD + koff0]);
-                kf1 = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HD + koff1]);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HDW + koff[ks]]);
             }
             s[t] = t < MAXT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (MAXT - 2)];
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], s[t], 0, 0, 0);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], s[t], 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], qf[ks], s[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // s[t][r] = S^T[key = 16t + 4lg + r][q = lr] (unscaled)
@@ -147,37 +169,39 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
 
-        f32x4 o[4];
+        f32x4 o[NDT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < NDT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < MAXT / 2; ++u) {
             const bf16x8 pb = pack8(s[2 * u], s[2 * u + 1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16_t* vp = Vs + u * 32 * HD + voff[dt];
-                const bf16x8 va = tr_frag2(vp, vp + 16 * HD);
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16_t* vp = Vs + u * 32 * HDW + voff[dt];
+                const bf16x8 va = tr_frag2(vp, vp + 16 * HDW);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[dt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         // o[dt][r] = O^T[d = 16dt + 4lg + r][q = lr]
         const int q = qt * 16 + lr;
-        uint2 pc[4];
+        uint2 pc[NDT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < NDT; ++dt) {
             pc[dt].x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
             pc[dt].y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
         }
-        const u32x4_t w01 = pair_pieces(pc[0], pc[1]), w23 = pair_pieces(pc[2], pc[3]);
+        u32x4_t w[NDT / 2];
+#pragma unroll
+        for (int j = 0; j < NDT / 2; ++j) w[j] = pair_pieces(pc[2 * j], pc[2 * j + 1]);
         if (q < N) {
-            bf16_t* op = out + ((size_t)b * N + q) * D + h * HD;
-            *reinterpret_cast<u32x4_t*>(op + pair_col(0, 1, lg)) = w01;
-            *reinterpret_cast<u32x4_t*>(op + pair_col(2, 3, lg)) = w23;
+            bf16_t* op = out + ((size_t)b * N + q) * D + h * HDP;
+#pragma unroll
+            for (int j = 0; j < NDT / 2; ++j) *reinterpret_cast<u32x4_t*>(op + pair_col(2 * j, 2 * j + 1, lg)) = w[j];
             if (lg == 0) lse[((size_t)b * H + h) * N + q] = (mx * c2 + __builtin_amdgcn_logf(sum)) * 0.69314718055994530942f;
         }
-        qf[0] = qn[0];
-        qf[1] = qn[1];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = qn[ks];
     }
 }
 
@@ -197,72 +221,96 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
 // Padding: query rows >= N carry lse' = +inf, so P = dS = 0 there; key rows >= N start the S^T accumulators of phase 2 at
 // -inf (tiles below MAXT-2 are all real keys); in phase 1 padded keys only feed dK/dV rows that are never stored.
 // MAXT = 2 * ceil(N / 32) key tiles is a template parameter: no run-time loop bounds.
-template <int MAXT, int WAVES, int WPE>
+template <int MAXT, int WAVES, int WPE, int HDP = 64>
 __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                        bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
+    using G = AttnGeo<HDP>;
+    constexpr int HDW = G::HDW, NKS = G::NKS, NDT = G::NDT, NCH = G::NCH, CPR = G::CPR, RPP = G::RPP;
     constexpr int NPAD = MAXT * 16;
     constexpr int TPW = (MAXT + WAVES - 1) / WAVES;        // key tiles (phase 1) / query tiles (phase 2) per wave
     bf16_t* R0 = reinterpret_cast<bf16_t*>(attn_smem);     // Q, then K
-    bf16_t* R1 = R0 + NPAD * HD;                            // dO, then V
-    float* lse_s = reinterpret_cast<float*>(R1 + NPAD * HD);   // [NPAD] lse * log2(e), +inf past N
+    bf16_t* R1 = R0 + NPAD * HDW;                           // dO, then V
+    float* lse_s = reinterpret_cast<float*>(R1 + NPAD * HDW);  // [NPAD] lse * log2(e), +inf past N
     float* dl_s = lse_s + NPAD;                                // [NPAD] delta * scale
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4, lq = lr >> 2, lp = lr & 3;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int D = H * HD, ld = 3 * D;
-    const bf16_t* base = qkv + (size_t)b * N * ld + h * HD;
-    const bf16_t* dobase = dout + (size_t)b * N * D + h * HD;
-    const bf16_t* obase = out + (size_t)b * N * D + h * HD;
+    const int D = H * HDP, ld = 3 * D;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * HDP;
+    const bf16_t* dobase = dout + (size_t)b * N * D + h * HDP;
+    const bf16_t* obase = out + (size_t)b * N * D + h * HDP;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(R0));
 
-    // DMA fill of the two images, a piece = 8 rows x 128 B: first = false: (Q, dO), true: (K, V)
+    // DMA fill of the two images, a piece = RPP rows x (HDW * 2) B: first = false: (Q, dO), true: (K, V)
     auto fill = [&](bool second) {
-        const int prow = lane >> 3, ppos = lane & 7;
-        for (int pc = wave; pc < 2 * (NPAD / 8); pc += WAVES) {
-            const int which = pc >= NPAD / 8 ? 1 : 0;
-            const int row = (pc - which * (NPAD / 8)) * 8 + prow;
+        const int prow = lane / CPR, ppos = lane % CPR;
+        for (int pc = wave; pc < 2 * (NPAD / RPP); pc += WAVES) {
+            const int which = pc >= NPAD / RPP ? 1 : 0;
+            const int row = (pc - which * (NPAD / RPP)) * RPP + prow;
             const int srow = row < N ? row : N - 1;
-            const int ch = (ppos ^ (row & 7)) << 3;
+            int c = ppos ^ G::sig(row);
+            if (CPR > NCH && c >= NCH) c -= 8;            // slots past the head's columns: any valid chunk, never read
+            const int ch = c << 3;
             const bf16_t* src = second ? base + (size_t)srow * ld + (1 + which) * D + ch
                                        : (which ? dobase + (size_t)srow * D + ch : base + (size_t)srow * ld + ch);
             glds16_v(src, lds0 + (unsigned)pc * 1024u);
         }
     };
     // this wave's own K, V rows of a key tile (phase 1), straight from global memory as MFMA fragments
-    auto load_kv = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2]) {
+    auto load_kv = [&](int kt, bf16x8 (&kf)[NKS], bf16x8 (&vf)[NKS]) {
         int key = kt * 16 + lr;
         key = key < N ? key : N - 1;
         const bf16_t* kp = base + (size_t)key * ld + D + 8 * lg;
-        kf[0] = *reinterpret_cast<const bf16x8*>(kp);
-        kf[1] = *reinterpret_cast<const bf16x8*>(kp + 32);
-        vf[0] = *reinterpret_cast<const bf16x8*>(kp + D);
-        vf[1] = *reinterpret_cast<const bf16x8*>(kp + D + 32);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(kp + D + 32 * ks);
+        }
     };
     // Up to 224 tokens a wave owns at most two tiles per phase (OWN): nothing that sits in LDS is fetched from global memory a
     // second time - delta takes dO from the LDS image, and the wave's own Q, dO fragments of phase 2 are read out of the
     // images before K and V replace them - and the first own K, V fragments travel with the fill.
-    constexpr int TOT = NPAD * 8, STR = WAVES * 64;
-    constexpr bool OWN = VITK_ATTN_OWN && TOT % STR == 0 && TOT / STR <= 4 && TPW <= 2;
-    bf16x8 kf[2], vf[2];
+    // delta items: (query row, 16-byte chunk slot), LPQ neighbouring lanes share a row (8 at 64 columns; 16 at 96, where the
+    // slots past the head contribute nothing)
+    constexpr int LPQ = CPR, LPQ_SH = HDW == 64 ? 3 : 4;
+    constexpr int TOT = NPAD * LPQ, STR = WAVES * 64;
+    constexpr bool OWN = VITK_ATTN_OWN && TOT % STR == 0 && TOT / STR <= (HDW == 64 ? 4 : 8) && TPW <= 2;
+    bf16x8 kf[NKS], vf[NKS];
     if constexpr (OWN) load_kv(wave, kf, vf);
     fill(false);
-    // delta and lse: item = (query row, 16-byte chunk), 8 neighbouring lanes share a row.  Up to 224 tokens NPAD * 8 items are
-    // an exact multiple of the block size and all loads of a thread are issued before the first is used; beyond, a plain loop
-    // (every trip is taken by whole 8-lane groups, so the shuffles stay inside active lanes).
+    auto row_dot = [&](const u32x4_t ra, const u32x4_t rc) {
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            part += __uint_as_float(ra[j] << 16) * __uint_as_float(rc[j] << 16);
+            part += __uint_as_float(ra[j] & 0xffff0000u) * __uint_as_float(rc[j] & 0xffff0000u);
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (LPQ == 16) part += __shfl_xor(part, 8, 64);
+        return part;
+    };
+    // delta and lse.  Up to 224 tokens the items are an exact multiple of the block size and all loads of a thread are issued
+    // before the first is used; beyond, a plain loop (every trip is taken by whole lane groups, so the shuffles stay inside
+    // active lanes).
     if constexpr (OWN) {
         constexpr int ITEMS = TOT / STR;
         u32x4_t rc[ITEMS];
         float lv[ITEMS];
+        const u32x4_t zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const int it = tid + i * STR;
-            int q = it >> 3;
+            int q = it >> LPQ_SH;
             q = q < N ? q : N - 1;
-            rc[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(obase + (size_t)q * D + (it & 7) * 8));
+            const int c = it & (LPQ - 1);
+            const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(obase + (size_t)q * D + (c < NCH ? c : 0) * 8));
+            rc[i] = c < NCH ? t : zero4;
             lv[i] = lse[((size_t)b * H + h) * N + q];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -270,23 +318,16 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const int it = tid + i * STR;
-            const int q = it >> 3;
-            const u32x4_t ra = *reinterpret_cast<const u32x4_t*>(R1 + q * HD + (((it & 7) ^ (q & 7)) << 3));
-            float part = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                part += __uint_as_float(ra[j] << 16) * __uint_as_float(rc[i][j] << 16);
-                part += __uint_as_float(ra[j] & 0xffff0000u) * __uint_as_float(rc[i][j] & 0xffff0000u);
-            }
-            part += __shfl_xor(part, 1, 64);
-            part += __shfl_xor(part, 2, 64);
-            part += __shfl_xor(part, 4, 64);
-            if ((it & 7) == 0) {
+            const int q = it >> LPQ_SH;
+            const int c = it & (LPQ - 1);
+            const u32x4_t ra = *reinterpret_cast<const u32x4_t*>(R1 + q * HDW + ((c ^ G::sig(q)) << 3));
+            const float part = row_dot(ra, rc[i]);
+            if (c == 0) {
                 dl_s[q] = part * scale;
                 lse_s[q] = q < N ? lv[i] * 1.44269504088896340736f : INFINITY;
             }
         }
-    } else if constexpr (TOT % STR == 0 && TOT / STR <= 4) {
+    } else if constexpr (HDW == 64 && TOT % STR == 0 && TOT / STR <= 4) {
         constexpr int ITEMS = TOT / STR;
         u32x4_t ra[ITEMS], rc[ITEMS];
         float lv[ITEMS];
@@ -303,38 +344,25 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         for (int i = 0; i < ITEMS; ++i) {
             const int it = tid + i * STR;
             const int q = it >> 3;
-            float part = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                part += __uint_as_float(ra[i][j] << 16) * __uint_as_float(rc[i][j] << 16);
-                part += __uint_as_float(ra[i][j] & 0xffff0000u) * __uint_as_float(rc[i][j] & 0xffff0000u);
-            }
-            part += __shfl_xor(part, 1, 64);
-            part += __shfl_xor(part, 2, 64);
-            part += __shfl_xor(part, 4, 64);
+            const float part = row_dot(ra[i], rc[i]);
             if ((it & 7) == 0) {
                 dl_s[q] = part * scale;
                 lse_s[q] = q < N ? lv[i] * 1.44269504088896340736f : INFINITY;
             }
         }
     } else {
+        const u32x4_t zero4 = {0u, 0u, 0u, 0u};
 #pragma unroll 2
         for (int it = tid; it < TOT; it += STR) {
-            const int q = it >> 3;
+            const int q = it >> LPQ_SH;
             const int qc = q < N ? q : N - 1;
-            const u32x4_t ra = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(dobase + (size_t)qc * D + (it & 7) * 8));
-            const u32x4_t rc = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(obase + (size_t)qc * D + (it & 7) * 8));
+            const int c = it & (LPQ - 1), cc = c < NCH ? c : 0;
+            u32x4_t ra = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(dobase + (size_t)qc * D + cc * 8));
+            const u32x4_t rc = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(obase + (size_t)qc * D + cc * 8));
+            if (c >= NCH) ra = zero4;
             const float lv = lse[((size_t)b * H + h) * N + qc];
-            float part = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                part += __uint_as_float(ra[j] << 16) * __uint_as_float(rc[j] << 16);
-                part += __uint_as_float(ra[j] & 0xffff0000u) * __uint_as_float(rc[j] & 0xffff0000u);
-            }
-            part += __shfl_xor(part, 1, 64);
-            part += __shfl_xor(part, 2, 64);
-            part += __shfl_xor(part, 4, 64);
-            if ((it & 7) == 0) {
+            const float part = row_dot(ra, rc);
+            if (c == 0) {
                 dl_s[q] = part * scale;
                 lse_s[q] = q < N ? lv * 1.44269504088896340736f : INFINITY;
             }
@@ -344,24 +372,26 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
     __syncthreads();
 
     const float c2 = scale * 1.44269504088896340736f;
-    const int foff0 = lr * HD + ((lg ^ (lr & 7)) << 3), foff1 = lr * HD + (((4 + lg) ^ (lr & 7)) << 3);   // b128 fragment of row 16t + lr
-    int toff[4];        // transposing-read offset of rows 4lg + lq (+16), columns 16dt + 4lp; same for every 32-row group
+    int foff[NKS];      // b128 fragment of row 16t + lr, K-slice s
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) toff[dt] = swz(4 * lg + lq, dt * 16 + 4 * lp);
+    for (int ks = 0; ks < NKS; ++ks) foff[ks] = lr * HDW + (((4 * ks + lg) ^ G::sig(lr)) << 3);
+    int toff[NDT];      // transposing-read offset of rows 4lg + lq (+16), columns 16dt + 4lp; same for every 32-row group
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) toff[dt] = G::swz(4 * lg + lq, dt * 16 + 4 * lp);
 
     // ---------------------------------------------------------------- phase 1: dK, dV of the owned key tiles (R0 = Q, R1 = dO)
 #pragma unroll 1
     for (int kt = wave; kt < MAXT; kt += WAVES) {
         if (!OWN || kt != wave) load_kv(kt, kf, vf);
-        f32x4 dv[4], dk[4];
+        f32x4 dv[NDT], dk[NDT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int dt = 0; dt < NDT; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         // up to 224 tokens the 32-query steps are unrolled: every LDS address becomes base + immediate (the rolled loop spends
         // a third of its vector instructions on address arithmetic)
-#pragma unroll(MAXT <= 14 ? MAXT / 2 : 1)
+#pragma unroll(MAXT <= 14 && HDP == 64 ? MAXT / 2 : 1)
         for (int st = 0; st < MAXT / 2; ++st) {
-            const bf16_t* Qp = R0 + st * 32 * HD;
-            const bf16_t* dOp = R1 + st * 32 * HD;
+            const bf16_t* Qp = R0 + st * 32 * HDW;
+            const bf16_t* dOp = R1 + st * 32 * HDW;
             bf16x8 pa, dsa;
             {   // stage 1: scores and their gradient for 32 queries x 16 keys
                 f32x4 pt[2], ds[2];
@@ -371,15 +401,18 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
                 const f32x4 d1 = *reinterpret_cast<const f32x4*>(&dl_s[st * 32 + 16 + 4 * lg]);
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) {
-                    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HD + foff0);
-                    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HD + foff1);
-                    const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HD + foff0);
-                    const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HD + foff1);
+                    bf16x8 qv[NKS], ov[NKS];
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        qv[ks] = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HDW + foff[ks]);
+                        ov[ks] = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HDW + foff[ks]);
+                    }
                     f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf[0], sacc, 0, 0, 0);
-                    dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, vf[0], dpacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf[1], sacc, 0, 0, 0);
-                    dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, vf[1], dpacc, 0, 0, 0);
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qv[ks], kf[ks], sacc, 0, 0, 0);
+                        dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ov[ks], vf[ks], dpacc, 0, 0, 0);
+                    }
                     // sacc[r] = S[q = 32st + 16qi + 4lg + r][key = lr]
                     const f32x4 lq4 = qi ? l1 : l0, dq4 = qi ? d1 : d0;
 #pragma unroll
@@ -394,9 +427,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             }
             // stage 2: dV^T += dO^T P, dK^T += Q^T dS
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 dotr = tr_frag2(dOp + toff[dt], dOp + 16 * HD + toff[dt]);
-                const bf16x8 qtr = tr_frag2(Qp + toff[dt], Qp + 16 * HD + toff[dt]);
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16x8 dotr = tr_frag2(dOp + toff[dt], dOp + 16 * HDW + toff[dt]);
+                const bf16x8 qtr = tr_frag2(Qp + toff[dt], Qp + 16 * HDW + toff[dt]);
                 dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr, pa, dv[dt], 0, 0, 0);
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsa, dk[dt], 0, 0, 0);
             }
@@ -404,41 +437,44 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         }
         // lane holds dK^T / dV^T [d = 16dt + 4lg + r][key = lr]
         const int key = kt * 16 + lr;
-        uint2 pk[4], pv[4];
+        uint2 pk[NDT], pv[NDT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < NDT; ++dt) {
             pk[dt].x = pack2bf(dk[dt][0], dk[dt][1]); pk[dt].y = pack2bf(dk[dt][2], dk[dt][3]);
             pv[dt].x = pack2bf(dv[dt][0], dv[dt][1]); pv[dt].y = pack2bf(dv[dt][2], dv[dt][3]);
         }
-        const u32x4_t k01 = pair_pieces(pk[0], pk[1]), k23 = pair_pieces(pk[2], pk[3]);
-        const u32x4_t v01 = pair_pieces(pv[0], pv[1]), v23 = pair_pieces(pv[2], pv[3]);
+        u32x4_t kw[NDT / 2], vw[NDT / 2];
+#pragma unroll
+        for (int j = 0; j < NDT / 2; ++j) { kw[j] = pair_pieces(pk[2 * j], pk[2 * j + 1]); vw[j] = pair_pieces(pv[2 * j], pv[2 * j + 1]); }
         if (key < N) {
-            bf16_t* rowp = dqkv + ((size_t)b * N + key) * ld + h * HD;
-            *reinterpret_cast<u32x4_t*>(rowp + D + pair_col(0, 1, lg)) = k01;
-            *reinterpret_cast<u32x4_t*>(rowp + D + pair_col(2, 3, lg)) = k23;
-            *reinterpret_cast<u32x4_t*>(rowp + 2 * D + pair_col(0, 1, lg)) = v01;
-            *reinterpret_cast<u32x4_t*>(rowp + 2 * D + pair_col(2, 3, lg)) = v23;
+            bf16_t* rowp = dqkv + ((size_t)b * N + key) * ld + h * HDP;
+#pragma unroll
+            for (int j = 0; j < NDT / 2; ++j) *reinterpret_cast<u32x4_t*>(rowp + D + pair_col(2 * j, 2 * j + 1, lg)) = kw[j];
+#pragma unroll
+            for (int j = 0; j < NDT / 2; ++j) *reinterpret_cast<u32x4_t*>(rowp + 2 * D + pair_col(2 * j, 2 * j + 1, lg)) = vw[j];
         }
     }
 
     // this wave's own Q, dO fragments of phase 2: out of the LDS images while they still hold Q and dO (OWN), else from global
-    auto load_q = [&](int qt, bf16x8 (&qf)[2], bf16x8 (&dof)[2]) {
+    auto load_q = [&](int qt, bf16x8 (&qf)[NKS], bf16x8 (&dof)[NKS]) {
         int q = qt * 16 + lr;
         q = q < N ? q : N - 1;
         const bf16_t* qp = base + (size_t)q * ld + 8 * lg;
         const bf16_t* dp = dobase + (size_t)q * D + 8 * lg;
-        qf[0] = *reinterpret_cast<const bf16x8*>(qp);
-        qf[1] = *reinterpret_cast<const bf16x8*>(qp + 32);
-        dof[0] = *reinterpret_cast<const bf16x8*>(dp);
-        dof[1] = *reinterpret_cast<const bf16x8*>(dp + 32);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dp + 32 * ks);
+        }
     };
-    auto lds_q = [&](int qt, bf16x8 (&qf)[2], bf16x8 (&dof)[2]) {
-        qf[0] = *reinterpret_cast<const bf16x8*>(R0 + qt * 16 * HD + foff0);
-        qf[1] = *reinterpret_cast<const bf16x8*>(R0 + qt * 16 * HD + foff1);
-        dof[0] = *reinterpret_cast<const bf16x8*>(R1 + qt * 16 * HD + foff0);
-        dof[1] = *reinterpret_cast<const bf16x8*>(R1 + qt * 16 * HD + foff1);
+    auto lds_q = [&](int qt, bf16x8 (&qf)[NKS], bf16x8 (&dof)[NKS]) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(R0 + qt * 16 * HDW + foff[ks]);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(R1 + qt * 16 * HDW + foff[ks]);
+        }
     };
-    bf16x8 qf[2], dof[2], qf2[2], dof2[2];
+    bf16x8 qf[NKS], dof[NKS], qf2[NKS], dof2[NKS];
     if constexpr (OWN) {
         lds_q(wave, qf, dof);
         if constexpr (TPW == 2) lds_q(wave + WAVES < MAXT ? wave + WAVES : wave, qf2, dof2);
@@ -461,30 +497,38 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
     for (int qt = wave; qt * 16 < N; qt += WAVES) {
         const int q = qt * 16 + lr;
         const float nl = -lse_s[q], dl = dl_s[q];
-        f32x4 dq[4];
+        f32x4 dq[NDT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(&R0[foff0]), kf1 = *reinterpret_cast<const bf16x8*>(&R0[foff1]);
-        bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(&R1[foff0]), vf1 = *reinterpret_cast<const bf16x8*>(&R1[foff1]);
+        for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 kn[NKS], vn[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            kn[ks] = *reinterpret_cast<const bf16x8*>(&R0[foff[ks]]);
+            vn[ks] = *reinterpret_cast<const bf16x8*>(&R1[foff[ks]]);
+        }
 #pragma unroll
         for (int u = 0; u < MAXT / 2; ++u) {
             f32x4 ds[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int t = 2 * u + e;
-                const bf16x8 a0 = kf0, a1 = kf1, b0 = vf0, b1 = vf1;
+                bf16x8 ka[NKS], va[NKS];
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) { ka[ks] = kn[ks]; va[ks] = vn[ks]; }
                 if (t + 1 < MAXT) {
-                    kf0 = *reinterpret_cast<const bf16x8*>(&R0[(t + 1) * 16 * HD + foff0]);
-                    kf1 = *reinterpret_cast<const bf16x8*>(&R0[(t + 1) * 16 * HD + foff1]);
-                    vf0 = *reinterpret_cast<const bf16x8*>(&R1[(t + 1) * 16 * HD + foff0]);
-                    vf1 = *reinterpret_cast<const bf16x8*>(&R1[(t + 1) * 16 * HD + foff1]);
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        kn[ks] = *reinterpret_cast<const bf16x8*>(&R0[(t + 1) * 16 * HDW + foff[ks]]);
+                        vn[ks] = *reinterpret_cast<const bf16x8*>(&R1[(t + 1) * 16 * HDW + foff[ks]]);
+                    }
                 }
                 f32x4 sacc = t < MAXT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (MAXT - 2)];
                 f32x4 dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], sacc, 0, 0, 0);
-                dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, dof[0], dpacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], sacc, 0, 0, 0);
-                dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, dof[1], dpacc, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[ks], qf[ks], sacc, 0, 0, 0);
+                    dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[ks], dof[ks], dpacc, 0, 0, 0);
+                }
                 // sacc[r] = S^T[key = 16t + 4lg + r][q = lr]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -494,9 +538,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             }
             const bf16x8 dsb = pack8(ds[0], ds[1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16_t* kp = R0 + u * 32 * HD + toff[dt];
-                const bf16x8 ktr = tr_frag2(kp, kp + 16 * HD);
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16_t* kp = R0 + u * 32 * HDW + toff[dt];
+                const bf16x8 ktr = tr_frag2(kp, kp + 16 * HDW);
                 dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dsb, dq[dt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -505,19 +549,24 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             if ((qt + WAVES) * 16 < N) load_q(qt + WAVES, qf, dof);
         }
         // dq[dt][r] = dQ^T[d = 16dt + 4lg + r][q = lr]
-        uint2 pq[4];
+        uint2 pq[NDT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < NDT; ++dt) {
             pq[dt].x = pack2bf(dq[dt][0], dq[dt][1]);
             pq[dt].y = pack2bf(dq[dt][2], dq[dt][3]);
         }
-        const u32x4_t q01 = pair_pieces(pq[0], pq[1]), q23 = pair_pieces(pq[2], pq[3]);
+        u32x4_t qw[NDT / 2];
+#pragma unroll
+        for (int j = 0; j < NDT / 2; ++j) qw[j] = pair_pieces(pq[2 * j], pq[2 * j + 1]);
         if (q < N) {
-            bf16_t* rowp = dqkv + ((size_t)b * N + q) * ld + h * HD;
-            *reinterpret_cast<u32x4_t*>(rowp + pair_col(0, 1, lg)) = q01;
-            *reinterpret_cast<u32x4_t*>(rowp + pair_col(2, 3, lg)) = q23;
+            bf16_t* rowp = dqkv + ((size_t)b * N + q) * ld + h * HDP;
+#pragma unroll
+            for (int j = 0; j < NDT / 2; ++j) *reinterpret_cast<u32x4_t*>(rowp + pair_col(2 * j, 2 * j + 1, lg)) = qw[j];
         }
-        if constexpr (OWN && TPW == 2) { qf[0] = qf2[0]; qf[1] = qf2[1]; dof[0] = dof2[0]; dof[1] = dof2[1]; }
+        if constexpr (OWN && TPW == 2) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) { qf[ks] = qf2[ks]; dof[ks] = dof2[ks]; }
+        }
     }
 }
 
@@ -770,6 +819,25 @@ int vitk_attention_generic_fwd(const void* qkv, void* out, float* lse, int B, in
     VITK_REQUIRE(head_dim >= 8 && head_dim <= GHDMAX && head_dim % 8 == 0, "attention_generic_fwd: head dim %d must be a multiple of 8 in [8, %d]",
                  head_dim, GHDMAX);
     VITK_REQUIRE(vitk_aligned(qkv, 16) && vitk_aligned(out, 16), "attention_generic_fwd: pointers must be 16-byte aligned");
+    if (head_dim == 96 && N <= 224) {
+        // heads of 96 columns (the model zero-pads 72 to 96) on the MFMA kernels: 256-byte LDS rows, one workgroup per compute unit
+        const int maxt = 2 * ((N + 31) / 32);
+        const size_t wsmem = (size_t)2 * maxt * 16 * 128 * sizeof(bf16_t);
+        static VitkLdsOnce wdone[16] = {};
+        hipStream_t s = (hipStream_t)stream;
+#define VITK_WFWD_CASE(T, W)                                                                                                \
+    case T: {                                                                                                               \
+        if (int rc_ = vitk_lds_once(wdone[T], (const void*)attn_fwd_kernel<T, W, 2, 96>, wsmem, "attention_fwd(96)")) return rc_; \
+        attn_fwd_kernel<T, W, 2, 96><<<B * H, W * 64, wsmem, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);         \
+    } break;
+        switch (maxt) {
+            VITK_WFWD_CASE(2, 4) VITK_WFWD_CASE(4, 4) VITK_WFWD_CASE(6, 4) VITK_WFWD_CASE(8, 4) VITK_WFWD_CASE(10, 7) VITK_WFWD_CASE(12, 7)
+            VITK_WFWD_CASE(14, 7)
+            default: vitk_set_error("attention_generic_fwd: unsupported token count %d", N); return VITK_EINVAL;
+        }
+#undef VITK_WFWD_CASE
+        return vitk_check_launch("attention_fwd(96)");
+    }
     const size_t smem = (size_t)2 * N * head_dim * sizeof(bf16_t);
 #define VITK_GFWD(G)                                                                                                                  \
     {                                                                                                                                 \
@@ -792,6 +860,25 @@ int vitk_attention_generic_bwd(const void* qkv, const void* out, const void* dou
                  head_dim, GHDMAX);
     VITK_REQUIRE(vitk_aligned(qkv, 16) && vitk_aligned(out, 16) && vitk_aligned(dout, 16) && vitk_aligned(dqkv, 16),
                  "attention_generic_bwd: pointers must be 16-byte aligned");
+    if (head_dim == 96 && N <= 224) {
+        const int maxt = 2 * ((N + 31) / 32);
+        const size_t wsmem = (size_t)2 * maxt * 16 * 128 * sizeof(bf16_t) + (size_t)2 * maxt * 16 * sizeof(float);
+        static VitkLdsOnce wdone[16] = {};
+        hipStream_t s = (hipStream_t)stream;
+#define VITK_WBWD_CASE(T, W)                                                                                                   \
+    case T: {                                                                                                               \
+        if (int rc_ = vitk_lds_once(wdone[T], (const void*)attn_bwd_res_kernel<T, W, 2, 96>, wsmem, "attention_bwd(96)")) return rc_; \
+        attn_bwd_res_kernel<T, W, 2, 96><<<B * H, W * 64, wsmem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, \
+                                                                   (bf16_t*)dqkv, N, H, scale);                             \
+    } break;
+        switch (maxt) {
+            VITK_WBWD_CASE(2, 2) VITK_WBWD_CASE(4, 4) VITK_WBWD_CASE(6, 6) VITK_WBWD_CASE(8, 4) VITK_WBWD_CASE(10, 5) VITK_WBWD_CASE(12, 6)
+            VITK_WBWD_CASE(14, 7)
+            default: vitk_set_error("attention_generic_bwd: unsupported token count %d", N); return VITK_EINVAL;
+        }
+#undef VITK_WBWD_CASE
+        return vitk_check_launch("attention_bwd(96)");
+    }
     const size_t smem = (size_t)2 * N * head_dim * sizeof(bf16_t) + (size_t)2 * N * sizeof(float);
 #define VITK_GBWD(G)                                                                                                                  \
     {                                                                                                                                 \

@@ -169,8 +169,9 @@ def _head_dim(qkv, B, N, H):
 
 
 def attention_fwd(qkv, B, N, H, scale):
-    """qkv bf16 [B*N, 3*H*d] -> (out bf16 [B*N, H*d], lse fp32 [B,H,N]).  d = 64: the MFMA kernels (<= 608 tokens); any other
-    multiple of 8 up to 96: the vector-arithmetic kernels (<= 256 tokens)."""
+    """qkv bf16 [B*N, 3*H*d] -> (out bf16 [B*N, H*d], lse fp32 [B,H,N]).  d = 64: the MFMA kernels (<= 608 tokens); d = 96 up to
+    224 tokens: the MFMA kernels with 256-byte LDS rows; any other multiple of 8 up to 96: the vector-arithmetic kernels
+    (<= 256 tokens)."""
     _chk(qkv, bf16, "qkv")
     d = _head_dim(qkv, B, N, H)
     out = torch.empty((B * N, H * d), dtype=bf16, device=qkv.device)

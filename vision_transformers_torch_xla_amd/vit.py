@@ -240,13 +240,16 @@ class VisionTransformer(nn.Module):
         self.num_patches = self.patch_embed.num_patches
         self.num_tokens = self.num_patches + self.num_prefix_tokens
         self.head_dim = embed_dim // num_heads
-        # Head dim 64 runs on the MFMA attention kernels (up to 608 tokens).  A smaller head dim (48: my_vit_mini,
-        # models/my_vit.py:84-93) runs on them too, ZERO-PADDED to 64: the qkv and proj GEMMs read bf16 weight copies with 64 rows /
-        # columns per head, the padding rows, columns and bias entries zero, so the padding lanes of q, k, v, the attention output
-        # and every gradient that flows through them are exactly zero and no result changes; parameters, gradients and state dicts
-        # keep timm's shapes.  Larger head dims (72: my_vit_xs) take the vector-arithmetic kernels (up to 256 tokens).
-        self._pad_heads = self.head_dim < 64
-        limit = 608 if self.head_dim <= 64 else 256
+        # Head dims 64 and 96 run on the MFMA attention kernels (64: up to 608 tokens, 96: up to 224).  Other head dims up to 96
+        # (48: my_vit_mini, 72: my_vit_xs, models/my_vit.py:84-125) run on them too, ZERO-PADDED to 64 / 96: the qkv and proj GEMMs
+        # read bf16 weight copies with that many rows / columns per head, the padding rows, columns and bias entries zero, so the
+        # padding lanes of q, k, v, the attention output and every gradient that flows through them are exactly zero and no
+        # result changes; parameters, gradients and state dicts keep timm's shapes.  Beyond 224 tokens a head between 64 and 96
+        # wide takes the vector-arithmetic kernels (up to 256 tokens), unpadded.
+        hd = self.head_dim
+        self._hd_pad = 64 if hd <= 64 else (96 if self.num_tokens <= 224 else hd)
+        self._pad_heads = self._hd_pad != hd
+        limit = 608 if hd <= 64 else 256
         if self.num_tokens > limit:
             raise VitkError(f"{self.num_tokens} tokens exceed the attention kernels' limit for head dim {self.head_dim} ({limit})")
         # registration order = timm's named_parameters() order (cls_token, pos_embed, dist_token: models/deit.py:41-43 adds the
@@ -449,18 +452,18 @@ class VisionTransformer(nn.Module):
     def _refresh_transposes(self):
         """[in, out] bf16 copies of the linears: the data-gradient GEMM dX = dY @ W runs as gemm_nt(dY, W^T)."""
         key = (self._flat["b"].data_ptr(), str(self._flat["b"].device))
-        H, hd = self.num_heads, self.head_dim
+        H, hd, hp = self.num_heads, self.head_dim, self._hd_pad
         if getattr(self, "_wt_plan_key", None) != key:
             pairs = []
             self._wpad = {}
             for n, src in self._wb.items():
                 if n == "patch_embed.proj.weight":      # the image needs no gradient
                     continue
-                if self._pad_heads and n.endswith("attn.qkv.weight"):        # [3 H hd, D] -> [3 H 64, D], zero rows between
-                    src = self._wpad[n] = torch.zeros((3 * H * 64, src.shape[1]), dtype=bf16, device=src.device)
-                    self._wpad[n[:-6] + "bias"] = torch.zeros(3 * H * 64, dtype=f32, device=src.device)
-                elif self._pad_heads and n.endswith("attn.proj.weight"):     # [D, H hd] -> [D, H 64], zero columns between
-                    src = self._wpad[n] = torch.zeros((src.shape[0], H * 64), dtype=bf16, device=src.device)
+                if self._pad_heads and n.endswith("attn.qkv.weight"):        # [3 H hd, D] -> [3 H hp, D], zero rows between
+                    src = self._wpad[n] = torch.zeros((3 * H * hp, src.shape[1]), dtype=bf16, device=src.device)
+                    self._wpad[n[:-6] + "bias"] = torch.zeros(3 * H * hp, dtype=f32, device=src.device)
+                elif self._pad_heads and n.endswith("attn.proj.weight"):     # [D, H hd] -> [D, H hp], zero columns between
+                    src = self._wpad[n] = torch.zeros((src.shape[0], H * hp), dtype=bf16, device=src.device)
                 dst = torch.empty((src.shape[1], src.shape[0]), dtype=bf16, device=src.device)
                 self._wt[n] = dst
                 pairs.append((src, dst))
@@ -471,11 +474,11 @@ class VisionTransformer(nn.Module):
             named = dict(zip(self._pnames, self._plist))
             for n, dst in self._wpad.items():
                 if n.endswith("qkv.weight"):
-                    dst.view(3 * H, 64, -1)[:, :hd].copy_(self._wb[n].view(3 * H, hd, -1))
+                    dst.view(3 * H, hp, -1)[:, :hd].copy_(self._wb[n].view(3 * H, hd, -1))
                 elif n.endswith("qkv.bias"):
-                    dst.view(3 * H, 64)[:, :hd].copy_(named[n].detach().view(3 * H, hd))
+                    dst.view(3 * H, hp)[:, :hd].copy_(named[n].detach().view(3 * H, hd))
                 else:
-                    dst.view(-1, H, 64)[:, :, :hd].copy_(self._wb[n].view(-1, H, hd))
+                    dst.view(-1, H, hp)[:, :, :hd].copy_(self._wb[n].view(-1, H, hd))
         ops.transpose_bf16_batched(self._wt_plan)
 
     def _views_ok(self):
@@ -729,23 +732,23 @@ class VisionTransformer(nn.Module):
         side = self._wgrad_stream()
         held, lagging = [], None        # operands of the current block; (event, operands) of the block before
 
-        Hh, hd = self.num_heads, self.head_dim
+        Hh, hd, hp = self.num_heads, self.head_dim, self._hd_pad
 
         def wgrad_gemm(dy, xin, wname, bname, ws_):
             """dW (+)= dy^T xin, dbias (+)= column sums of dy, into the flat gradient buffer.  With zero-padded heads the qkv / proj
             products come out in the padded shape: the real rows / columns are copied (or added) across afterwards."""
             if self._pad_heads and wname.endswith("attn.qkv.weight"):
-                tw = torch.empty((3 * Hh * 64, xin.shape[1]), dtype=f32, device=dy.device)
-                tb = torch.empty(3 * Hh * 64, dtype=f32, device=dy.device)
+                tw = torch.empty((3 * Hh * hp, xin.shape[1]), dtype=f32, device=dy.device)
+                tb = torch.empty(3 * Hh * hp, dtype=f32, device=dy.device)
                 ops.gemm_tn(dy, xin, tw, dbias=tb, accumulate=False, ws=ws_)
                 gw, gb = g[wname].view(3 * Hh, hd, -1), g[bname].view(3 * Hh, hd)
-                sw, sb = tw.view(3 * Hh, 64, -1)[:, :hd], tb.view(3 * Hh, 64)[:, :hd]
+                sw, sb = tw.view(3 * Hh, hp, -1)[:, :hd], tb.view(3 * Hh, hp)[:, :hd]
                 (gw.add_(sw), gb.add_(sb)) if acc else (gw.copy_(sw), gb.copy_(sb))
             elif self._pad_heads and wname.endswith("attn.proj.weight"):
-                tw = torch.empty((dy.shape[1], Hh * 64), dtype=f32, device=dy.device)
+                tw = torch.empty((dy.shape[1], Hh * hp), dtype=f32, device=dy.device)
                 tb = torch.empty(dy.shape[1], dtype=f32, device=dy.device)
                 ops.gemm_tn(dy, xin, tw, dbias=tb, accumulate=False, ws=ws_)
-                gw, sw = g[wname].view(-1, Hh, hd), tw.view(-1, Hh, 64)[:, :, :hd]
+                gw, sw = g[wname].view(-1, Hh, hd), tw.view(-1, Hh, hp)[:, :, :hd]
                 (gw.add_(sw), g[bname].add_(tb)) if acc else (gw.copy_(sw), g[bname].copy_(tb))
             else:
                 ops.gemm_tn(dy, xin, g[wname], dbias=g[bname], accumulate=acc, ws=ws_)
