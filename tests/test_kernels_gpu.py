@@ -257,7 +257,8 @@ def test_gemm_rejects_bad_shapes(device):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 198, 12), (1, 577, 2), (3, 17, 1), (2, 50, 2), (1, 224, 1), (1, 225, 1), (2, 1, 1), (1, 608, 1), (1, 300, 2), (2, 400, 1), (1, 512, 1), (1, 257, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 198, 12), (1, 577, 2), (3, 17, 1), (2, 50, 2), (1, 224, 1), (1, 225, 1), (2, 1, 1), (1, 608, 1), (1, 300, 2), (2, 400, 1), (1, 512, 1), (1, 257, 1),
+                                   (1, 193, 2), (2, 208, 1), (1, 209, 1), (1, 192, 1)])   # either side of the 13-tile kernels (193 ... 208 tokens)
 def test_attention_fwd_bwd(device, B, N, H):
     from oracle import ref_ops as R
     ops = _ops()

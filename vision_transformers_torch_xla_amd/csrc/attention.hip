@@ -19,6 +19,9 @@ void vitk_prof_end(void* stream);
 #ifndef VITK_ATTN_OWN
 #define VITK_ATTN_OWN 1
 #endif
+#ifndef VITK_ATTN_ODD
+#define VITK_ATTN_ODD 1
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
@@ -70,13 +73,16 @@ static __device__ __forceinline__ int pair_col(int dtA, int dtB, int lg) { retur
 // padding (C = -inf + finite stays -inf), which is the whole masking cost.
 // WAVES waves per workgroup and WPE waves per SIMD asked of the compiler: 7 and 4 up to 224 keys (13 query tiles at 197
 // tokens = at most 2 per wave; two workgroups per CU), 4 and 1 beyond.
-template <int MAXT, int WAVES, int WPE, int HDP = 64>
+// ODD: N <= (MAXT - 1) * 16, the last key tile is all padding (197 tokens are 13 tiles): its scores are not computed and it enters
+// the 32-key P V products as zeros.  The images keep MAXT * 16 rows (the transposing reads take 32 rows at a time).
+template <int MAXT, int WAVES, int WPE, int HDP = 64, bool ODD = false>
 __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                    float* __restrict__ lse, int N, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char attn_smem[];
     using G = AttnGeo<HDP>;
     constexpr int HDW = G::HDW, NKS = G::NKS, NDT = G::NDT, NCH = G::NCH, CPR = G::CPR, RPP = G::RPP;
     constexpr int NPAD = MAXT * 16;
+    constexpr int KT = MAXT - (ODD ? 1 : 0);               // key tiles that hold real keys
     bf16_t* Ks = reinterpret_cast<bf16_t*>(attn_smem);
     bf16_t* Vs = Ks + NPAD * HDW;
 
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tail0[i][r] = ((MAXT - 2 + i) * 16 + 4 * lg + r < N) ? 0.f : -INFINITY;
+        for (int r = 0; r < 4; ++r) tail0[i][r] = ((KT - 2 + i) * 16 + 4 * lg + r < N) ? 0.f : -INFINITY;
     int koff[NKS];      // b128 fragment of row 16t + lr, K-slice s; (16t + lr) & 7 == lr & 7
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) koff[ks] = lr * HDW + (((4 * ks + lg) ^ G::sig(lr)) << 3);
@@ -136,15 +142,15 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(&Ks[koff[ks]]);
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
+        for (int t = 0; t < KT; ++t) {
             bf16x8 a[NKS];
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) a[ks] = kf[ks];
-            if (t + 1 < MAXT) {
+            if (t + 1 < KT) {
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(&Ks[(t + 1) * 16 * HDW + koff[ks]]);
             }
-            s[t] = t < MAXT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (MAXT - 2)];
+            s[t] = t < KT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (KT - 2)];
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], qf[ks], s[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -152,13 +158,13 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
         // s[t][r] = S^T[key = 16t + 4lg + r][q = lr] (unscaled)
         float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-        for (int t = 1; t < MAXT; ++t) mx = fmaxf(fmaxf(mx, s[t][0]), fmaxf(fmaxf(s[t][1], s[t][2]), s[t][3]));
+        for (int t = 1; t < KT; ++t) mx = fmaxf(fmaxf(mx, s[t][0]), fmaxf(fmaxf(s[t][1], s[t][2]), s[t][3]));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float nmc = -mx * c2;
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t)
+        for (int t = 0; t < KT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c2, nmc));
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+        if constexpr (ODD) s[MAXT - 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         f32x4 o[NDT];
 #pragma unroll
@@ -221,7 +228,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
 // Padding: query rows >= N carry lse' = +inf, so P = dS = 0 there; key rows >= N start the S^T accumulators of phase 2 at
 // -inf (tiles below MAXT-2 are all real keys); in phase 1 padded keys only feed dK/dV rows that are never stored.
 // MAXT = 2 * ceil(N / 32) key tiles is a template parameter: no run-time loop bounds.
-template <int MAXT, int WAVES, int WPE, int HDP = 64>
+// ODD: N <= (MAXT - 1) * 16 - tile MAXT-1 is all padding as a key tile and as a query tile: no wave owns it, and where it is the
+// second half of a 32-row step its scores are not computed and it enters the 32-deep products as zeros.
+template <int MAXT, int WAVES, int WPE, int HDP = 64, bool ODD = false>
 __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                        const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                        bf16_t* __restrict__ dqkv, int N, int H, float scale) {
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
     using G = AttnGeo<HDP>;
     constexpr int HDW = G::HDW, NKS = G::NKS, NDT = G::NDT, NCH = G::NCH, CPR = G::CPR, RPP = G::RPP;
     constexpr int NPAD = MAXT * 16;
+    constexpr int KT = MAXT - (ODD ? 1 : 0);               // tiles that hold real tokens
     constexpr int TPW = (MAXT + WAVES - 1) / WAVES;        // key tiles (phase 1) / query tiles (phase 2) per wave
     bf16_t* R0 = reinterpret_cast<bf16_t*>(attn_smem);     // Q, then K
     bf16_t* R1 = R0 + NPAD * HDW;                           // dO, then V
@@ -380,15 +390,16 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
     for (int dt = 0; dt < NDT; ++dt) toff[dt] = G::swz(4 * lg + lq, dt * 16 + 4 * lp);
 
     // ---------------------------------------------------------------- phase 1: dK, dV of the owned key tiles (R0 = Q, R1 = dO)
+    constexpr bool UNR = MAXT <= 14 && HDP == 64;           // the 32-query steps of phase 1 are unrolled
 #pragma unroll 1
-    for (int kt = wave; kt < MAXT; kt += WAVES) {
+    for (int kt = wave; kt < KT; kt += WAVES) {
         if (!OWN || kt != wave) load_kv(kt, kf, vf);
         f32x4 dv[NDT], dk[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) { dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         // up to 224 tokens the 32-query steps are unrolled: every LDS address becomes base + immediate (the rolled loop spends
         // a third of its vector instructions on address arithmetic)
-#pragma unroll(MAXT <= 14 && HDP == 64 ? MAXT / 2 : 1)
+#pragma unroll(UNR ? MAXT / 2 : 1)
         for (int st = 0; st < MAXT / 2; ++st) {
             const bf16_t* Qp = R0 + st * 32 * HDW;
             const bf16_t* dOp = R1 + st * 32 * HDW;
@@ -401,6 +412,11 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
                 const f32x4 d1 = *reinterpret_cast<const f32x4*>(&dl_s[st * 32 + 16 + 4 * lg]);
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi) {
+                    if (ODD && UNR && st == MAXT / 2 - 1 && qi == 1) {      // the padding tile: a constant after unrolling
+                        pt[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        ds[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        continue;
+                    }
                     bf16x8 qv[NKS], ov[NKS];
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tail0[i][r] = ((MAXT - 2 + i) * 16 + 4 * lg + r < N) ? 0.f : -INFINITY;
+        for (int r = 0; r < 4; ++r) tail0[i][r] = ((KT - 2 + i) * 16 + 4 * lg + r < N) ? 0.f : -INFINITY;
 #pragma unroll 1
     for (int qt = wave; qt * 16 < N; qt += WAVES) {
         const int q = qt * 16 + lr;
@@ -512,17 +528,21 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int t = 2 * u + e;
+                if (t >= KT) {                                  // the padding tile
+                    ds[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    continue;
+                }
                 bf16x8 ka[NKS], va[NKS];
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) { ka[ks] = kn[ks]; va[ks] = vn[ks]; }
-                if (t + 1 < MAXT) {
+                if (t + 1 < KT) {
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
                         kn[ks] = *reinterpret_cast<const bf16x8*>(&R0[(t + 1) * 16 * HDW + foff[ks]]);
                         vn[ks] = *reinterpret_cast<const bf16x8*>(&R1[(t + 1) * 16 * HDW + foff[ks]]);
                     }
                 }
-                f32x4 sacc = t < MAXT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (MAXT - 2)];
+                f32x4 sacc = t < KT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (KT - 2)];
                 f32x4 dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
@@ -581,6 +601,13 @@ int vitk_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int
     hipStream_t s = (hipStream_t)stream;
     static VitkLdsOnce attr_done[40] = {};
     const bool pr = vitk_prof_begin(stream, 8.0 * (double)B * (double)N * (double)H * HD, VITK_PROF_ATTN_FWD);
+    if (VITK_ATTN_ODD && maxt == 14 && N <= 13 * 16) {       // 193 ... 208 tokens (ViT at 224 px: 197, distilled 198): 13 tiles, the 14th is padding
+        static VitkLdsOnce odd_done = {};
+        if (int rc_ = vitk_lds_once(odd_done, (const void*)attn_fwd_kernel<14, 7, 4, 64, true>, smem, "attention_fwd")) return rc_;
+        attn_fwd_kernel<14, 7, 4, 64, true><<<B * H, 7 * 64, smem, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+        if (pr) vitk_prof_end(stream);
+        return vitk_check_launch("attention_fwd");
+    }
 #define VITK_FWD_CASE(T, W, E)                                                                                              \
     case T: {                                                                                                               \
         if (int rc_ = vitk_lds_once(attr_done[T], (const void*)attn_fwd_kernel<T, W, E>, smem, "attention_fwd")) return rc_;          \
@@ -615,6 +642,14 @@ int vitk_attention_bwd(const void* qkv, const void* out, const void* dout, const
     hipStream_t s = (hipStream_t)stream;
     static VitkLdsOnce attr_done[40] = {};
     const bool pr = vitk_prof_begin(stream, 16.0 * (double)B * (double)N * (double)H * HD, VITK_PROF_ATTN_BWD);
+    if (VITK_ATTN_ODD && maxt == 14 && N <= 13 * 16) {       // 13 tiles of real tokens (see vitk_attention_fwd)
+        static VitkLdsOnce odd_done = {};
+        if (int rc_ = vitk_lds_once(odd_done, (const void*)attn_bwd_res_kernel<14, 7, 4, 64, true>, smem, "attention_bwd")) return rc_;
+        attn_bwd_res_kernel<14, 7, 4, 64, true><<<B * H, 7 * 64, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                                                                          (bf16_t*)dqkv, N, H, scale);
+        if (pr) vitk_prof_end(stream);
+        return vitk_check_launch("attention_bwd");
+    }
 #define VITK_BWD_CASE(T, W, E)                                                                                                 \
     case T: {                                                                                                               \
         if (int rc_ = vitk_lds_once(attr_done[T], (const void*)attn_bwd_res_kernel<T, W, E>, smem, "attention_bwd")) return rc_;          \
@@ -830,6 +865,12 @@ int vitk_attention_generic_fwd(const void* qkv, void* out, float* lse, int B, in
         if (int rc_ = vitk_lds_once(wdone[T], (const void*)attn_fwd_kernel<T, W, 2, 96>, wsmem, "attention_fwd(96)")) return rc_; \
         attn_fwd_kernel<T, W, 2, 96><<<B * H, W * 64, wsmem, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);         \
     } break;
+        if (VITK_ATTN_ODD && maxt == 14 && N <= 13 * 16) {       // 13 tiles of real tokens (see vitk_attention_fwd)
+            static VitkLdsOnce odd_done = {};
+            if (int rc_ = vitk_lds_once(odd_done, (const void*)attn_fwd_kernel<14, 7, 2, 96, true>, wsmem, "attention_fwd(96)")) return rc_;
+            attn_fwd_kernel<14, 7, 2, 96, true><<<B * H, 7 * 64, wsmem, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, scale);
+            return vitk_check_launch("attention_fwd(96)");
+        }
         switch (maxt) {
             VITK_WFWD_CASE(2, 4) VITK_WFWD_CASE(4, 4) VITK_WFWD_CASE(6, 4) VITK_WFWD_CASE(8, 4) VITK_WFWD_CASE(10, 7) VITK_WFWD_CASE(12, 7)
             VITK_WFWD_CASE(14, 7)
@@ -871,6 +912,13 @@ int vitk_attention_generic_bwd(const void* qkv, const void* out, const void* dou
         attn_bwd_res_kernel<T, W, 2, 96><<<B * H, W * 64, wsmem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, \
                                                                    (bf16_t*)dqkv, N, H, scale);                             \
     } break;
+        if (VITK_ATTN_ODD && maxt == 14 && N <= 13 * 16) {
+            static VitkLdsOnce odd_done = {};
+            if (int rc_ = vitk_lds_once(odd_done, (const void*)attn_bwd_res_kernel<14, 7, 2, 96, true>, wsmem, "attention_bwd(96)")) return rc_;
+            attn_bwd_res_kernel<14, 7, 2, 96, true><<<B * H, 7 * 64, wsmem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                                                                              (bf16_t*)dqkv, N, H, scale);
+            return vitk_check_launch("attention_bwd(96)");
+        }
         switch (maxt) {
             VITK_WBWD_CASE(2, 2) VITK_WBWD_CASE(4, 4) VITK_WBWD_CASE(6, 6) VITK_WBWD_CASE(8, 4) VITK_WBWD_CASE(10, 5) VITK_WBWD_CASE(12, 6)
             VITK_WBWD_CASE(14, 7)
