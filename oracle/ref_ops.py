@@ -85,7 +85,8 @@ class _Attention(torch.autograd.Function):
     """softmax(q k^T * scale) v over heads of dim d, explicit forward/backward.
 
     With emulate=True the bf16 roundings of the HIP kernels are reproduced: P is rounded before P@V and before
-    P^T@dO, dS is rounded before dS@K and dS^T@Q, O is rounded on output; everything else is fp32."""
+    P^T@dO, dS / scale is rounded before its products with K and Q (their sums are scaled in fp32), O is rounded on output;
+    everything else is fp32."""
 
     @staticmethod
     def forward(ctx, qkv, H, scale, emulate):
@@ -120,11 +121,11 @@ def _attention_backward(q, k, v, o, lse, do_, scale, emulate):
     pb = rb(p) if emulate else p
     dv = pb.transpose(-1, -2) @ do
     dp = do @ v.transpose(-1, -2)
-    ds = p * (dp - delta) * scale
+    ds = p * (dp - delta)              # dS / scale: the kernels store this (bf16) and scale the dQ, dK sums once, in fp32
     if emulate:
         ds = rb(ds)
-    dq = ds @ k
-    dk = ds.transpose(-1, -2) @ q
+    dq = (ds @ k) * scale
+    dk = (ds.transpose(-1, -2) @ q) * scale
     return torch.stack([dq, dk, dv], dim=0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * H * d)
 
 

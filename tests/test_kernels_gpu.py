@@ -287,6 +287,10 @@ def test_attention_fwd_bwd(device, B, N, H):
     errs = {}
     for which, name in enumerate("qkv"):
         sl = slice(which * D, (which + 1) * D)
+        if N == 1 and name in "qk":        # one key: P = 1 and dS = dP - delta = 0 exactly; both sides hold rounding residue only
+            assert got[..., sl].abs().max().item() <= 1e-5 and want[..., sl].abs().max().item() <= 1e-5, name
+            errs[name] = 0.0
+            continue
         errs[name] = rel_l2(got[..., sl], rb(want[..., sl]))
         assert rel_l2(got[..., sl], res[False][1][..., sl]) <= 1e-2, name
     print(f"attention backward B={B} N={N} H={H}: " + ", ".join(f"d{k} {v:.1e}" for k, v in errs.items()))

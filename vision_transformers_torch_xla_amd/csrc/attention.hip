@@ -215,7 +215,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
 // ----------------------------------------------------------------------------------------------- backward
 // Two barrier-free phases; the scores are recomputed in the second instead of passing dS
 // between waves:
-//   phase 1, a wave owns key tiles:   S = Q K^T, dP = dO V^T (key on the lane), P = 2^(S c - lse'), dS = P (dP - delta) scale,
+//   phase 1, a wave owns key tiles:   S = Q K^T, dP = dO V^T (key on the lane), P = 2^((S - lse / scale) c), dS = P (dP - delta) scale
+//                                     (-lse / scale and -delta are the start values of the S and dP accumulators, scale is applied to dK, dQ),
 //                                     dV^T += dO^T P, dK^T += Q^T dS   (Q^T, dO^T by transposing reads)
 //   phase 2, a wave owns query tiles: S^T = K Q^T, dP^T = V dO^T (query on the lane), same P and dS, dQ^T += K^T dS^T.
 // What all waves share goes through LDS ([NPAD][64] images, chunk XOR-swizzled by row & 7, filled by DMA): Q and dO in
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_fwd_kernel(const bf16_t*
 // MFMAs; beyond (up to 608 tokens = 157 KB) one 8-wave workgroup owns the CU.
 // The owned key tiles of phase 1 are processed one after the other, each step in two stages that reuse the same registers
 // (b128 fragments of Q, dO for S and dP; then their transposed fragments for dV, dK).
-// Padding: query rows >= N carry lse' = +inf, so P = dS = 0 there; key rows >= N start the S^T accumulators of phase 2 at
+// Padding: query rows >= N carry -lse / scale = -inf, so P = dS = 0 there; key rows >= N start the S^T accumulators of phase 2 at
 // -inf (tiles below MAXT-2 are all real keys); in phase 1 padded keys only feed dK/dV rows that are never stored.
 // MAXT = 2 * ceil(N / 32) key tiles is a template parameter: no run-time loop bounds.
 // ODD: N <= (MAXT - 1) * 16 - tile MAXT-1 is all padding as a key tile and as a query tile: no wave owns it, and where it is the
@@ -242,8 +243,9 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
     constexpr int TPW = (MAXT + WAVES - 1) / WAVES;        // key tiles (phase 1) / query tiles (phase 2) per wave
     bf16_t* R0 = reinterpret_cast<bf16_t*>(attn_smem);     // Q, then K
     bf16_t* R1 = R0 + NPAD * HDW;                           // dO, then V
-    float* lse_s = reinterpret_cast<float*>(R1 + NPAD * HDW);  // [NPAD] lse * log2(e), +inf past N
-    float* dl_s = lse_s + NPAD;                                // [NPAD] delta * scale
+    float* lse_s = reinterpret_cast<float*>(R1 + NPAD * HDW);  // [NPAD] -lse / scale, -inf past N
+    float* dl_s = lse_s + NPAD;                                // [NPAD] -delta
+    const float inv_scale = 1.0f / scale;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -333,8 +335,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             const u32x4_t ra = *reinterpret_cast<const u32x4_t*>(R1 + q * HDW + ((c ^ G::sig(q)) << 3));
             const float part = row_dot(ra, rc[i]);
             if (c == 0) {
-                dl_s[q] = part * scale;
-                lse_s[q] = q < N ? lv[i] * 1.44269504088896340736f : INFINITY;
+                dl_s[q] = -part;
+                lse_s[q] = q < N ? -lv[i] * inv_scale : -INFINITY;
             }
         }
     } else if constexpr (HDW == 64 && TOT % STR == 0 && TOT / STR <= 4) {
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             const int q = it >> 3;
             const float part = row_dot(ra[i], rc[i]);
             if ((it & 7) == 0) {
-                dl_s[q] = part * scale;
-                lse_s[q] = q < N ? lv[i] * 1.44269504088896340736f : INFINITY;
+                dl_s[q] = -part;
+                lse_s[q] = q < N ? -lv[i] * inv_scale : -INFINITY;
             }
         }
     } else {
@@ -373,8 +375,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
             const float lv = lse[((size_t)b * H + h) * N + qc];
             const float part = row_dot(ra, rc);
             if (c == 0) {
-                dl_s[q] = part * scale;
-                lse_s[q] = q < N ? lv * 1.44269504088896340736f : INFINITY;
+                dl_s[q] = -part;
+                lse_s[q] = q < N ? -lv * inv_scale : -INFINITY;
             }
         }
     }
@@ -423,19 +425,19 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
                         qv[ks] = *reinterpret_cast<const bf16x8*>(Qp + qi * 16 * HDW + foff[ks]);
                         ov[ks] = *reinterpret_cast<const bf16x8*>(dOp + qi * 16 * HDW + foff[ks]);
                     }
-                    f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f}, dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    // the row constants are the accumulators' start values: S - lse / scale and dP - delta come out of the chains
+                    f32x4 sacc = qi ? l1 : l0, dpacc = qi ? d1 : d0;
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
                         sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qv[ks], kf[ks], sacc, 0, 0, 0);
                         dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ov[ks], vf[ks], dpacc, 0, 0, 0);
                     }
-                    // sacc[r] = S[q = 32st + 16qi + 4lg + r][key = lr]
-                    const f32x4 lq4 = qi ? l1 : l0, dq4 = qi ? d1 : d0;
+                    // sacc[r] = S[q = 32st + 16qi + 4lg + r][key = lr] - lse[q] / scale
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, -lq4[r]));
+                        const float pp = __builtin_amdgcn_exp2f(sacc[r] * c2);
                         pt[qi][r] = pp;
-                        ds[qi][r] = pp * __builtin_fmaf(dpacc[r], scale, -dq4[r]);
+                        ds[qi][r] = pp * dpacc[r];           // dS / scale: dK is scaled once, below
                     }
                 }
                 pa = pack8(pt[0], pt[1]);     // contraction slot (lg, j): q = 4lg + j | 16 + 4lg + j - 4
@@ -456,6 +458,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         uint2 pk[NDT], pv[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
+            dk[dt] *= scale;
             pk[dt].x = pack2bf(dk[dt][0], dk[dt][1]); pk[dt].y = pack2bf(dk[dt][2], dk[dt][3]);
             pv[dt].x = pack2bf(dv[dt][0], dv[dt][1]); pv[dt].y = pack2bf(dv[dt][2], dv[dt][3]);
         }
@@ -512,7 +515,11 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
 #pragma unroll 1
     for (int qt = wave; qt * 16 < N; qt += WAVES) {
         const int q = qt * 16 + lr;
-        const float nl = -lse_s[q], dl = dl_s[q];
+        const float nl = lse_s[q], dl = dl_s[q];          // -lse / scale and -delta of this lane's query: accumulator start values
+        const f32x4 s0 = {nl, nl, nl, nl}, d0 = {dl, dl, dl, dl};
+        f32x4 tl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tl[i] = tail0[i] + nl;
         f32x4 dq[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -542,8 +549,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
                         vn[ks] = *reinterpret_cast<const bf16x8*>(&R1[(t + 1) * 16 * HDW + foff[ks]]);
                     }
                 }
-                f32x4 sacc = t < KT - 2 ? (f32x4){0.f, 0.f, 0.f, 0.f} : tail0[t - (KT - 2)];
-                f32x4 dpacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 sacc = t < KT - 2 ? s0 : tl[t - (KT - 2)];
+                f32x4 dpacc = d0;
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
                     sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[ks], qf[ks], sacc, 0, 0, 0);
@@ -551,10 +558,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
                 }
                 // sacc[r] = S^T[key = 16t + 4lg + r][q = lr]
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pp = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, nl));
-                    ds[e][r] = pp * __builtin_fmaf(dpacc[r], scale, -dl);
-                }
+                for (int r = 0; r < 4; ++r) ds[e][r] = __builtin_amdgcn_exp2f(sacc[r] * c2) * dpacc[r];      // dS / scale
             }
             const bf16x8 dsb = pack8(ds[0], ds[1]);
 #pragma unroll
@@ -572,6 +576,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void attn_bwd_res_kernel(const bf1
         uint2 pq[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
+            dq[dt] *= scale;
             pq[dt].x = pack2bf(dq[dt][0], dq[dt][1]);
             pq[dt].y = pack2bf(dq[dt][2], dq[dt][3]);
         }
@@ -785,7 +790,7 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const bf16_t* __r
     bf16_t* R0 = reinterpret_cast<bf16_t*>(attn_smem);       // Q, then K
     bf16_t* R1 = R0 + N * hd;                                 // dO, then V
     float* lse_s = reinterpret_cast<float*>(R1 + N * hd);     // [N] lse * log2(e)
-    float* dl_s = lse_s + N;                                  // [N] rowsum(dO * O) * scale
+    float* dl_s = lse_s + N;                                  // [N] rowsum(dO * O)
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int D = H * hd, ld = 3 * D;
     const bf16_t* base = qkv + (size_t)b * N * ld + h * hd;
@@ -802,11 +807,12 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const bf16_t* __r
         float part = 0.f;
 #pragma unroll
         for (int d = 0; d < GHD; ++d) part = __builtin_fmaf(a[d], c[d], part);
-        dl_s[t] = part * scale;
+        dl_s[t] = part;
         lse_s[t] = lse[((size_t)b * H + h) * N + t] * 1.44269504088896340736f;
     }
     __syncthreads();
-    // phase 1: thread = key j.  dV[j] = sum_i bf16(P[i,j]) dO[i];  dK[j] = sum_i bf16(dS[i,j]) Q[i]
+    // phase 1: thread = key j.  dV[j] = sum_i bf16(P[i,j]) dO[i];  dK[j] = scale * sum_i bf16(dS[i,j] / scale) Q[i]
+    // (dS is rounded before the scale, as in the MFMA kernels, where the scale is applied once to the dK / dQ accumulators)
     if (t < N) {
         float kr[GHD], vr[GHD], dk[GHD], dv[GHD];
         g_load_row(base + (size_t)t * ld + D, hd, kr);
@@ -816,10 +822,12 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const bf16_t* __r
 #pragma unroll 2
         for (int i = 0; i < N; ++i) {
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(g_dot(kr, R0 + i * hd, hd), c2, -lse_s[i]));
-            const float ds = p * __builtin_fmaf(g_dot(vr, R1 + i * hd, hd), scale, -dl_s[i]);
+            const float ds = p * (g_dot(vr, R1 + i * hd, hd) - dl_s[i]);
             g_axpy(g_round_bf16(p), R1 + i * hd, hd, dv);
             g_axpy(g_round_bf16(ds), R0 + i * hd, hd, dk);
         }
+#pragma unroll
+        for (int d = 0; d < GHD; ++d) dk[d] *= scale;
         bf16_t* rowp = dqkv + ((size_t)b * N + t) * ld + h * hd;
         g_store_row(rowp + D, hd, dk);
         g_store_row(rowp + 2 * D, hd, dv);
@@ -839,9 +847,11 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const bf16_t* __r
 #pragma unroll 4
         for (int j = 0; j < N; ++j) {
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(g_dot(qr, R0 + j * hd, hd), c2, nl));
-            const float ds = p * __builtin_fmaf(g_dot(dor, R1 + j * hd, hd), scale, -dl);
+            const float ds = p * (g_dot(dor, R1 + j * hd, hd) - dl);
             g_axpy(g_round_bf16(ds), R0 + j * hd, hd, dq);
         }
+#pragma unroll
+        for (int d = 0; d < GHD; ++d) dq[d] *= scale;
         g_store_row(dqkv + ((size_t)b * N + t) * ld + h * hd, hd, dq);
     }
 }
