@@ -42,6 +42,7 @@ struct GemmNTParams {
     const bf16_t* aux; int ldaux;
     const float* pos; int patches; int prefix;
     int tiles_n; int num_tiles;
+    int tiles_m; int cb;          // persistent kernel: row tiles; column tiles per block of the tile order (cb = tiles_n: row-major)
     const int* smap; int rps;     // BIAS_RES only: output / residual row of GEMM row m is smap[m / rps] * rps + m % rps
     unsigned* sched;              // persistent kernel: this launch's tile counters, [8] per XCD + [8] = workgroups that have left
 };
@@ -342,10 +343,16 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
     const bf16_t* sB = p.B;
     unsigned voA[4], voB[4];
     auto aim = [&](int v, int& m0, int& n0) {
+        // tile order: blocks of cb column tiles, row-major inside a block (the last block may be narrower)
         const int tile = xcd_remap(v, p.num_tiles);
-        const int tm_ = tile / p.tiles_n;
+        const int full = p.tiles_m * p.cb;
+        const int blk = tile / full;
+        const int rem = tile - blk * full;
+        const int c0 = blk * p.cb;
+        const int width = p.tiles_n - c0 < p.cb ? p.tiles_n - c0 : p.cb;
+        const int tm_ = rem / width;
         m0 = tm_ * LBM;
-        n0 = (tile - tm_ * p.tiles_n) * LBN;
+        n0 = (c0 + rem - tm_ * width) * LBN;
         sA = p.A + (size_t)m0 * p.lda;
         sB = p.B + (size_t)n0 * p.ldb;
         const int ra_max = p.M - 1 - m0, rb_max = p.N - 1 - n0;       // rows past the edge re-read the last valid row
@@ -1063,6 +1070,28 @@ static int vitk_num_cus() {
     return cache[dev];
 }
 
+// Tile order of the persistent NT kernel.  An XCD walks a contiguous range of the order, so row-major order makes every XCD
+// sweep ALL column tiles: the whole weight matrix cycles through its 4 MB L2 once per tile round, and when it does not fit
+// (N x K x 2 B above about 2.5 MB beside the streaming operands) every round fetches it again from the Infinity Cache.  Cutting
+// the order into blocks of cb column tiles keeps a slice of the weights resident at the price of fetching the activation panel
+// once per block; cb minimises the estimate A x blocks + (slice resident ? 8 slices : rounds x 8 slices).
+static int ntp_column_block(int tiles_m, int tiles_n, int K, int cus) {
+    static const char* bud_s = getenv("VITK_NT_SLICE_KB");
+    static const double budget = (bud_s ? atof(bud_s) : 2560.0) * 1024.0;
+    const double a_bytes = (double)tiles_m * LBM * K * 2.0, col_bytes = (double)LBN * K * 2.0;
+    const double rounds = (double)tiles_m * tiles_n / (double)cus;
+    int best = tiles_n;
+    double best_cost = 0.0;
+    for (int nb = 1; nb <= tiles_n && nb <= 6; ++nb) {
+        const int cb = (tiles_n + nb - 1) / nb;
+        if (nb > 1 && (tiles_n + cb - 1) / cb != nb) continue;
+        const double slice = cb * col_bytes;
+        const double cost = a_bytes * nb + (slice <= budget ? 8.0 * slice * nb : rounds * 8.0 * slice);
+        if (nb == 1 || cost < best_cost) { best = cb; best_cost = cost; }
+    }
+    return best;
+}
+
 extern "C" {
 
 static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, int epilogue,
@@ -1112,7 +1141,9 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_NT);       // every return below closes the bracket
     if (big) {
         p.tiles_n = (N + LBN - 1) / LBN;
-        p.num_tiles = ((M + LBM - 1) / LBM) * p.tiles_n;
+        p.tiles_m = (M + LBM - 1) / LBM;
+        p.num_tiles = p.tiles_m * p.tiles_n;
+        p.cb = ntp_column_block(p.tiles_m, p.tiles_n, K, cus);
         const size_t smem = NTP_LDS;
         const int grid = p.num_tiles < cus ? p.num_tiles : cus;      // one persistent workgroup per CU
 #define VITK_LAUNCH_BIG(E)                                                                                              \
