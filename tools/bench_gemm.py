@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the libvitk GEMMs on the ViT-B/16 (B=512) shapes: TFLOP/s per shape, random bf16 operands.
-usage: python tools/bench_gemm.py [nt|tn|all] [reps]"""
+usage: python tools/bench_gemm.py [nt|tn|all] [reps] [nodb]     (nodb: weight gradients without the bias gradient)"""
 import sys
 from pathlib import Path
 
@@ -32,6 +32,7 @@ def timeit(fn, reps):
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    with_db = not (len(sys.argv) > 3 and sys.argv[3] == "nodb")
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
@@ -50,7 +51,7 @@ def main():
             a, b = rnd(m, n), rnd(m, k)
             out = torch.empty((n, k), dtype=torch.float32, device=dev)
             db = torch.empty(n, dtype=torch.float32, device=dev)
-            ms = timeit(lambda: ops.gemm_tn(a, b, out, dbias=db), reps)
+            ms = timeit(lambda: ops.gemm_tn(a, b, out, dbias=db if with_db else None), reps)
             print(f"tn {name:10s} M={m} N={n:5d} K={k:5d}  {ms:7.3f} ms  {2.0 * m * n * k / ms / 1e9:7.1f} TFLOP/s", flush=True)
 
 

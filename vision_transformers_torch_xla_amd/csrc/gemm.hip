@@ -818,9 +818,15 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
     const int lq = lr >> 2, lp = lr & 3;
     const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr(lsm));
 
-    const int task = xcd_remap(blockIdx.x, p.ntasks);
-    const int range = task / p.T, tile = task - range * p.T;
-    const int tn_ = tile / p.tiles_k;
+    // Execution order (an XCD takes a contiguous stretch of it): range-major; inside a range the tile index of the NARROWER
+    // operand runs fastest, so the tasks that share a column panel of the wider one (most of the bytes) are neighbours and sit
+    // on one XCD.  Tasks keep their number range * T + n tile * tiles_k + k tile for the slabs.
+    const int pos = xcd_remap(blockIdx.x, p.ntasks);
+    const int range = pos / p.T, idx = pos - range * p.T;
+    const int tiles_n = p.T / p.tiles_k;
+    const int tn_ = p.tiles_k > tiles_n ? idx % tiles_n : idx / p.tiles_k;
+    const int tile = p.tiles_k > tiles_n ? tn_ * p.tiles_k + idx / tiles_n : idx;
+    const int task = range * p.T + tile;
     const int n0 = tn_ * 256, k0 = (tile - tn_ * p.tiles_k) * 256;
     const int step0 = (int)(((long long)range * p.steps_total) / p.R);
     const int nsteps = (int)(((long long)(range + 1) * p.steps_total) / p.R) - step0;      // >= 2 (host)
@@ -832,6 +838,10 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
     // made those the stragglers of every launch: +6 %.)
     const int ktile = tile - tn_ * p.tiles_k;
     const bool cs_role = COLSUM && ktile < 2;
+    // Where the k tile runs fastest, the tasks that share a column panel of A are the k tiles of one n tile - two of them with
+    // the sums, the rest without, i.e. 3 % faster per step: they drift apart until the panel has left L2 between the first and
+    // the last reader.  The rest run the sums too (results dropped): a launch ends with its slowest task anyway.
+    const bool cs_pace = COLSUM && (cs_role || p.tiles_k <= tiles_n);
     const int tperm = COLSUM ? (((ktile & 1) << 2) | wn) : 0;       // accumulator tile tm holds row tile tm ^ tperm
 
     // staging: a piece (one wave-instruction, 1 KB) is 2 rows x 512 B; wave w, piece j -> local rows (4w+j)*2 + lane/32;
@@ -956,7 +966,7 @@ __global__ __launch_bounds__(512) void gemm_tnb_kernel(const GemmTNBigParams p) 
     }
     };
     // one copy of the loop with the column sums, one without (wave-uniform choice; both meet the same barriers)
-    if (cs_role) run(itag<1>{});
+    if (cs_pace) run(itag<1>{});
     else run(itag<0>{});
 
     // partial tile -> slab (streaming): lane = row lr of MFMA tile tm, 4 consecutive k
