@@ -148,6 +148,39 @@ def test_gemm_nt_epilogues(device, M, N, K):
     assert rel_l2(resd.float(), rb(res.float() + acc)) <= REL_TOL
 
 
+@pytest.mark.parametrize("per,samples,kept", [(197, 12, 9), (128, 10, 7), (130, 9, 9), (300, 6, 4), (577, 4, 3), (50, 24, 17), (17, 64, 40)])
+def test_gemm_nt_res_scatter(device, per, samples, kept):
+    """bias + residual over the kept samples of a stochastic-depth branch: GEMM row c * per + j goes to row smap[c] * per + j of the
+    residual stream, scaled by rowscale[c]; the other samples' rows stay as they are.  Samples of 128 rows and more take the
+    per-tile lookup of the persistent kernel (sample boundaries inside a wave's 128 rows, the last sample, ragged last tile), the
+    smaller ones the per-row path"""
+    from vision_transformers_torch_xla_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(per * 31 + kept)
+    N, K = 320, 128
+    M = kept * per
+    a = _randb((M, K), g)
+    b = _randb((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g) * 0.1
+    x = _randb((samples * per, N), g)
+    smap = torch.randperm(samples, generator=g)[:kept].sort().values.to(torch.int32)
+    rs = torch.rand(kept, generator=g) + 0.5
+    acc = (a.double() @ b.double().t() + bias.double()).float()
+    want = x.float().clone()
+    for c in range(kept):
+        rows = slice(int(smap[c]) * per, (int(smap[c]) + 1) * per)
+        want[rows] += rs[c] * acc[c * per:(c + 1) * per]
+    xd = x.to(device).clone()
+    ops.gemm_nt(a.to(device), b.to(device), epilogue=_lib.EPI_BIAS_RES, bias=bias.to(device), res=xd, out=xd, rowscale=rs.to(device),
+                rows_per_group=per, smap=smap.to(device), rows_per_sample=per)
+    got = xd.float().cpu()
+    dropped = torch.ones(samples, dtype=torch.bool)
+    dropped[smap.long()] = False
+    keep_rows = (~dropped).repeat_interleave(per)
+    assert torch.equal(got[~keep_rows], x.float()[~keep_rows])            # dropped samples: bit for bit untouched
+    assert rel_l2(got[keep_rows], rb(want)[keep_rows]) <= REL_TOL
+
+
 def test_gemm_nt_concurrent_streams(device):
     """The persistent kernel deals its tiles through per-stream counters that it leaves zeroed: launches that overlap on two streams,
     and repeated launches on one, give bit for bit what a lone launch gives"""

@@ -515,13 +515,42 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         // the previous store: fetch it by hand, 8 pieces (64 rows) ahead, to keep HBM latency out of the store loop.
         constexpr bool SIDE = EPI == VITK_EPI_BIAS_RES || EPI == VITK_EPI_DGELU || EPI == VITK_EPI_MUL;
         const int ecol = n0 + wn * 64 + (lane & 7) * 8;
+        // Stochastic depth (BIAS_RES): GEMM row m belongs to kept sample m / rps, whose rows live at sample smap[.] of the residual
+        // stream and are scaled by rowscale[.].  A wave's 128 rows span at most two samples when a sample has >= 128 rows: the two
+        // samples' row offsets and scales are looked up ONCE per tile (wave-uniform), and a row picks between them with one
+        // compare - instead of two integer divisions and two dependent loads in front of every side fetch and every store.
+        bool fastmap = false;
+        int map_bnd = 0, map_off0 = 0, map_off1 = 0;
+        float map_rs0 = 1.0f, map_rs1 = 1.0f;
+        if (EPI == VITK_EPI_BIAS_RES && (p.smap != nullptr || p.rowscale != nullptr)) {
+            const int per = p.smap != nullptr ? p.rps : p.rows_per_group;
+            fastmap = per >= 128 && (p.smap == nullptr || p.rowscale == nullptr || p.rps == p.rows_per_group);
+            if (fastmap) {
+                int mw = __builtin_amdgcn_readfirstlane(m0) + wm * 128;
+                mw = mw < p.M ? mw : p.M - 1;
+                const int c0 = mw / per;
+                map_bnd = (c0 + 1) * per;
+                const int c1 = map_bnd < p.M ? c0 + 1 : c0;
+                if (p.smap != nullptr) {
+                    map_off0 = __builtin_amdgcn_readfirstlane((p.smap[c0] - c0) * per);
+                    map_off1 = __builtin_amdgcn_readfirstlane((p.smap[c1] - (c0 + 1)) * per);
+                }
+                if (p.rowscale != nullptr) {
+                    map_rs0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.rowscale[c0])));
+                    map_rs1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.rowscale[c1])));
+                }
+            }
+        }
         u32x4 side[SIDE ? 8 : 1];
         auto fetch_side = [&](int tm_base) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 int m = m0 + wm * 128 + (tm_base + (i >> 1)) * 16 + (i & 1) * 8 + srow;
                 m = m < p.M ? m : p.M - 1;
-                if (EPI == VITK_EPI_BIAS_RES && p.smap != nullptr) { const int c = m / p.rps; m = p.smap[c] * p.rps + (m - c * p.rps); }
+                if (EPI == VITK_EPI_BIAS_RES && p.smap != nullptr) {
+                    if (fastmap) m += m >= map_bnd ? map_off1 : map_off0;
+                    else { const int c = m / p.rps; m = p.smap[c] * p.rps + (m - c * p.rps); }
+                }
                 const int n = ecol < p.N ? ecol : 0;
                 side[SIDE ? i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(nt_side_ptr<EPI>(p, m, n)));
             }
@@ -554,8 +583,14 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
                     int orow = m;
                     const float* posrow = nullptr;
                     if (EPI == VITK_EPI_BIAS_RES) {
-                        if (p.rowscale != nullptr) rs = p.rowscale[m / p.rows_per_group];
-                        if (p.smap != nullptr) { const int c = m / p.rps; orow = p.smap[c] * p.rps + (m - c * p.rps); }
+                        if (fastmap) {
+                            const bool nx = m >= map_bnd;
+                            rs = nx ? map_rs1 : map_rs0;
+                            orow = m + (nx ? map_off1 : map_off0);
+                        } else {
+                            if (p.rowscale != nullptr) rs = p.rowscale[m / p.rows_per_group];
+                            if (p.smap != nullptr) { const int c = m / p.rps; orow = p.smap[c] * p.rps + (m - c * p.rps); }
+                        }
                     }
                     if (EPI == VITK_EPI_PATCH) {
                         const int b = m / p.patches, pi = m - b * p.patches;
