@@ -8,6 +8,8 @@ is implemented; other --opt names raise.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -156,7 +158,8 @@ class FusedAdamW(torch.optim.Optimizer):
             if "step" in st:
                 st["step"] = torch.tensor(float(self._steps))
         if model is not None and hasattr(model, "_refresh_transposes"):
-            model._refresh_transposes()                      # bf16 copies were written by the kernel itself
+            # bf16 copies were written by the kernel itself; the transposed ones go to the side stream (VITK_DEFER_WT=0: this stream)
+            model._refresh_transposes(defer=os.environ.get("VITK_DEFER_WT", "1") != "0")
             model._weights_version = model._version_key()
         return loss
 

@@ -356,10 +356,14 @@ class VisionTransformer(nn.Module):
         self._grad_valid = False
         # transposed weight copies and their descriptor table belong to THIS bf16 buffer: a table kept across a re-flatten
         # would name freed memory if the allocator ever handed the old address out again
+        pending = getattr(self, "_wt_ready", None)
+        if pending is not None:     # a transposition queued on the side stream still writes the copies dropped below
+            torch.cuda.current_stream().wait_event(pending)
         self._wt = {}
         self._wpad = {}
         self._wt_plan = None
         self._wt_plan_key = None
+        self._wt_ready = None       # event behind a transposition that runs on the side stream; backward waits for it
         self._weights_version = None
         # bucket boundaries for gradient reduction: grads below boundary k are final once stage k of backward is done
         self._layer_end = {}
@@ -449,8 +453,11 @@ class VisionTransformer(nn.Module):
         new._compact_droppath = self._compact_droppath
         return new
 
-    def _refresh_transposes(self):
-        """[in, out] bf16 copies of the linears: the data-gradient GEMM dX = dY @ W runs as gemm_nt(dY, W^T)."""
+    def _refresh_transposes(self, defer=False):
+        """[in, out] bf16 copies of the linears: the data-gradient GEMM dX = dY @ W runs as gemm_nt(dY, W^T).
+        defer: nothing before the next backward reads the copies, so the optimizer asks for them on the side stream of the
+        weight-gradient GEMMs (idle during the forward pass), where the launch fills compute units that the forward GEMMs' last
+        tile rounds leave empty; the next backward waits for `_wt_ready`."""
         key = (self._flat["b"].data_ptr(), str(self._flat["b"].device))
         H, hd, hp = self.num_heads, self.head_dim, self._hd_pad
         if getattr(self, "_wt_plan_key", None) != key:
@@ -479,7 +486,21 @@ class VisionTransformer(nn.Module):
                     dst.view(3 * H, hp)[:, :hd].copy_(named[n].detach().view(3 * H, hd))
                 else:
                     dst.view(-1, H, hp)[:, :, :hd].copy_(self._wb[n].view(-1, H, hd))
-        ops.transpose_bf16_batched(self._wt_plan)
+        cur = torch.cuda.current_stream()
+        if self._wt_ready is not None:           # a transposition still queued on the side stream writes the same copies
+            cur.wait_event(self._wt_ready)
+            self._wt_ready = None
+        side = self._wgrad_stream() if defer else None
+        if side is None:
+            ops.transpose_bf16_batched(self._wt_plan)
+            return
+        ev = torch.cuda.Event()
+        ev.record(cur)                           # the bf16 weights are complete once everything queued so far has run
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            ops.transpose_bf16_batched(self._wt_plan)
+            self._wt_ready = torch.cuda.Event()
+            self._wt_ready.record(side)
 
     def _views_ok(self):
         p0, off0 = self._plist[0], self._offs[self._pnames[0]]
@@ -650,6 +671,9 @@ class VisionTransformer(nn.Module):
         scale = self.head_dim ** -0.5
         self._ensure_grad_buffer()
         g = self._gview
+        if self._wt_ready is not None:           # transposed weights written on the side stream after the last optimizer step
+            torch.cuda.current_stream().wait_event(self._wt_ready)
+            self._wt_ready = None
         # grads: overwrite unless a previous backward since the last zero_grad already wrote the buffer
         acc = self._grad_valid and all(p.grad is not None for p in self._plist)
         tail = saved["tail"]
