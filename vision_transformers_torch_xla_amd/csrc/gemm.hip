@@ -45,12 +45,6 @@ struct GemmNTParams {
     int tiles_m; int cb;          // persistent kernel: row tiles; column tiles per block of the tile order (cb = tiles_n: row-major)
     const int* smap; int rps;     // BIAS_RES only: output / residual row of GEMM row m is smap[m / rps] * rps + m % rps
     unsigned* sched;              // persistent kernel: this launch's tile counters, [8] per XCD + [8] = workgroups that have left
-    // persistent kernel, left-over tile round cut along K: tasks [0, t_full) are whole tiles, every tile from t_full on is `split`
-    // tasks of nkp K-steps each, which leave fp32 partial tiles in part_ws; the task that finishes last (part_cnt, one word per such
-    // tile) sums them in part order and runs the epilogue.  split = 1: t_full = num_tasks = num_tiles, nothing is cut.
-    int t_full, num_tasks, split, nkp;
-    float* part_ws;
-    unsigned* part_cnt;
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Remap so that every XCD works on a
@@ -330,22 +324,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTParams p) {
 #define NTP_DRAIN 16                 // output stores a wave issues per full tile, at least (16 row groups, one each)
 #define NTP_LDS (4 * LTILE * 2 + 8 * 16 * 64 * 4)   // bytes: operand image + 4 KB of epilogue staging per wave
 
-// 16-byte accesses that other compute units' caches cannot shadow: sc1 stores are written through to memory and sc1 loads are served
-// from there, which is how the fp32 partial tiles of a tile cut along K travel between workgroups (on any XCD) inside one launch.
-// The loads are invisible to hipcc's wait counting: nt_wait_loaded() waits for all of them and ties the loaded registers to the wait.
-// Addressed as uniform base (scalar registers) + 32-bit lane offset, so that no 64-bit per-lane address has to live anywhere.
-static __device__ __forceinline__ void st_sc1(const float* sbase, unsigned voff, const f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-static __device__ __forceinline__ f32x4 ld_sc1(const float* sbase, unsigned voff) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
-    return v;
-}
-static __device__ __forceinline__ void nt_wait_loaded(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
-}
-
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lsm[];   // [2 buffers][A tile | B tile], [8 waves][16][64] fp32
@@ -364,21 +342,9 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
     const bf16_t* sA = p.A;          // staging state: operand panels of the tile being requested
     const bf16_t* sB = p.B;
     unsigned voA[4], voB[4];
-    auto aim = [&](int v, int& m0, int& n0, int& part, int& tail) {
-        // task v -> tile (and, in the left-over round, which part of its K range): every XCD walks its share of the whole tiles
-        // first and its share of the parts after them; the parts of one tile are neighbours (same XCD, same time)
-        int tile;
-        if (v < p.t_full) {
-            tile = xcd_remap(v, p.t_full);
-            part = -1;
-            tail = 0;
-        } else {
-            const int w = xcd_remap(v - p.t_full, p.num_tasks - p.t_full);
-            tail = w / p.split;
-            part = w - tail * p.split;
-            tile = p.t_full + tail;
-        }
+    auto aim = [&](int v, int& m0, int& n0) {
         // tile order: blocks of cb column tiles, row-major inside a block (the last block may be narrower)
+        const int tile = xcd_remap(v, p.num_tiles);
         const int full = p.tiles_m * p.cb;
         const int blk = tile / full;
         const int rem = tile - blk * full;
@@ -387,9 +353,8 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         const int tm_ = rem / width;
         m0 = tm_ * LBM;
         n0 = (c0 + rem - tm_ * width) * LBN;
-        const int kofs = part > 0 ? part * p.nkp * GBK : 0;
-        sA = p.A + (size_t)m0 * p.lda + kofs;
-        sB = p.B + (size_t)n0 * p.ldb + kofs;
+        sA = p.A + (size_t)m0 * p.lda;
+        sB = p.B + (size_t)n0 * p.ldb;
         const int ra_max = p.M - 1 - m0, rb_max = p.N - 1 - n0;       // rows past the edge re-read the last valid row
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -457,9 +422,8 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
     };
     int v = blockIdx.x, vn = 0;
     int m0, n0, nm0 = 0, nn0 = 0;
-    int part_c, tail_c, part_n = -1, tail_n = 0;        // part of the K range (-1: a whole tile) and left-over tile index: current, next
     issue_claim();
-    aim(v, m0, n0, part_c, tail_c);
+    aim(v, m0, n0);
     stageA(0, 0);
     stageB(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -479,9 +443,8 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         bool has_next = false;       // known from the first barrier of the tile on
-        const int nk_c = part_c < 0 ? nk : p.nkp;
 
-        for (int kt = 0; kt < nk_c; ++kt) {
+        for (int kt = 0; kt < nk; ++kt) {
             const bf16_t* cA = lsm + par * 2 * LTILE;
             const bf16_t* cB = cA + LTILE;
             const bf16_t* nA = lsm + (par ^ 1) * 2 * LTILE;
@@ -521,15 +484,15 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
             asm volatile("" ::: "memory");
             if (kt == 0) {
                 vn = __builtin_amdgcn_readfirstlane((int)*mailbox);
-                has_next = (unsigned)vn < (unsigned)p.num_tasks;
+                has_next = (unsigned)vn < (unsigned)p.num_tiles;
             }
-            if (kt + 2 < nk_c) {
+            if (kt + 2 < nk) {
                 stageA(kt + 2, par);
                 pend_k = kt + 2; pend_par = par;
             } else if (has_next) {
-                if (kt + 2 == nk_c) aim(vn, nm0, nn0, part_n, tail_n);
-                stageA(kt + 2 - nk_c, par);
-                pend_k = kt + 2 - nk_c; pend_par = par;
+                if (kt + 2 == nk) aim(vn, nm0, nn0);
+                stageA(kt + 2 - nk, par);
+                pend_k = kt + 2 - nk; pend_par = par;
             }
             // phase (1,1): fetch the first fragments of the next K-step (after the last tile: stale LDS, never used)
             mma(faO, fbO, 1);
@@ -543,71 +506,6 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
 
         if (pend_k >= 0) { stageB(pend_k, pend_par); pend_k = -1; }      // before the stores: vmcnt counts in issue order
         if (has_next) issue_claim();                                      // likewise: the claim is older than every store
-        // A part of a tile cut along K: leave the fp32 partial tile (accumulator layout, 1 KB per wave instruction) in memory and
-        // take a ticket; the part whose ticket is the last one sums all parts IN PART ORDER - its own from registers - so the
-        // result does not depend on which part came last, and goes on to the epilogue.  Nobody waits for anybody.  The hand-off
-        // is the measured one: sc1 stores, every storing wave waits for them, a workgroup barrier, ONE lane's device-scope atomic
-        // add; the waves of the workgroup whose add came last load (sc1) behind a barrier that follows the add's return.
-        bool do_epi = true;
-        if (part_c >= 0) {
-            // lane offset inside a part: 16 bytes per lane, 8 KB per accumulator tile; made opaque so that it is computed here and
-            // not kept in a register through the K loops
-            unsigned loff = threadIdx.x * 16u;
-            asm volatile("" : "+v"(loff));
-            const float* mine = p.part_ws + ((size_t)(tail_c * p.split + part_c) << 16);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) st_sc1(mine + i * 2048, loff, acc[i >> 2][i & 3]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (wave == 0 && lane == 0) mailbox[1] = atomicAdd(&p.part_cnt[tail_c], 1u);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const unsigned ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)mailbox[1]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                 // wave 0's staging (the mailbox) is free for its epilogue again
-            asm volatile("" ::: "memory");
-            do_epi = ticket == (unsigned)p.split - 1u;
-            if (do_epi) {
-                if (wave == 0 && lane == 0) p.part_cnt[tail_c] = 0u;       // for the next launch on this stream
-                const float* all = p.part_ws + ((size_t)(tail_c * p.split) << 16);
-                // the other parts, in part order: foreign part f is part f + (f >= own); with fewer than four parts the unused
-                // slots re-read an existing part (never summed)
-                const int last = p.split - 1;
-                const int j0 = part_c <= 0 ? 1 : 0;
-                const int j1 = last < 2 ? j0 : (part_c <= 1 ? 2 : 1);
-                const int j2 = last < 3 ? j0 : (part_c <= 2 ? 3 : 2);
-                const float* f0 = all + ((size_t)j0 << 16);
-                const float* f1 = all + ((size_t)j1 << 16);
-                const float* f2 = all + ((size_t)j2 << 16);
-                const bool three = p.split > 2, four = p.split > 3;
-#pragma unroll
-                for (int i0 = 0; i0 < 32; i0 += 4) {
-                    f32x4 L0[4], L1[4], L2[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        L0[i] = ld_sc1(f0 + (i0 + i) * 2048, loff);
-                        L1[i] = ld_sc1(f1 + (i0 + i) * 2048, loff);
-                        L2[i] = ld_sc1(f2 + (i0 + i) * 2048, loff);
-                    }
-                    nt_wait_loaded(L0[0], L0[1], L0[2], L0[3]);
-                    nt_wait_loaded(L1[0], L1[1], L1[2], L1[3]);
-                    nt_wait_loaded(L2[0], L2[1], L2[2], L2[3]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        f32x4& own = acc[(i0 + i) >> 2][(i0 + i) & 3];
-                        // terms in part order 0, 1, 2, 3: part j is `own` where j == part_c, else the foreign slot that holds it
-                        f32x4 r = part_c == 0 ? own : L0[i];
-                        r += part_c == 1 ? own : (part_c < 1 ? L0[i] : L1[i]);
-                        if (three) r += part_c == 2 ? own : (part_c < 2 ? L1[i] : L2[i]);
-                        if (four) r += part_c == 3 ? own : L2[i];
-                        own = r;
-                    }
-                }
-            }
-        }
-        if (do_epi) {
         // Epilogue.  The MFMA layout (lane = row lr, 4 columns) would store 32-byte pieces of 16 rows per instruction, and
         // the store path is paid per lane-access, not per byte.  Transpose through this wave's private 4 KB of LDS instead
         // (fp32, so the arithmetic is unchanged): 16 rows x 64 columns at a time, read back as lane = (row lane/8, 8
@@ -704,14 +602,11 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
                 }
             }
         }
-        }
         if (!has_next) break;
-        loose = do_epi && m0 + LBM <= p.M && n0 + LBN <= p.N;      // a full tile: every lane stored all 16 pieces
+        loose = m0 + LBM <= p.M && n0 + LBN <= p.N;      // a full tile: every lane stored all 16 pieces
         v = vn;
         m0 = nm0;
         n0 = nn0;
-        part_c = part_n;
-        tail_c = tail_n;
     }
     // the last workgroup to leave zeroes the counters for the next launch that uses them
     if (wave == 0 && lane == 0) {
@@ -1173,32 +1068,11 @@ static TnPlan tn_plan(int M, int N, int K) {
 // array's name is only a stand-in: its device address comes from hipGetSymbolAddress, once per device.
 #define NTP_SCHED_SLOTS 256
 static __device__ __align__(256) unsigned ntp_sched[NTP_SCHED_SLOTS * 16];
-struct NtpSchedDev { unsigned* base = nullptr; int used = 0; void* streams[NTP_SCHED_SLOTS]; float* part[NTP_SCHED_SLOTS]; };
+struct NtpSchedDev { unsigned* base = nullptr; int used = 0; void* streams[NTP_SCHED_SLOTS]; };
 static std::mutex g_ntp_sched_mu;
 static NtpSchedDev g_ntp_sched[64];
-#define NTP_PART_TILES 128           // a left-over round is cut along K when it has at most half as many tiles as there are workgroups
 
-static unsigned* ntp_sched_slot(void* stream, int* slot = nullptr);
-
-// Partial-tile buffer of a (device, stream) for the left-over round cut along K: [512 B of per-tile tickets | parts x 256 KB].
-// Library-owned like the tile counters (launches of one stream run one after the other; the kernel leaves the tickets zeroed);
-// allocated by the first launch that cuts a round, which is the one place where this library calls hipMalloc.
-static float* ntp_part_buffer(int slot, int parts) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(g_ntp_sched_mu);
-    NtpSchedDev& d = g_ntp_sched[dev];
-    if (d.part[slot] == nullptr) {
-        void* ptr = nullptr;
-        const size_t bytes = 512 + (size_t)parts * 65536 * sizeof(float);
-        if (hipMalloc(&ptr, bytes) != hipSuccess || ptr == nullptr) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(ptr, 0, 512) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
-        d.part[slot] = (float*)ptr;
-    }
-    return d.part[slot];
-}
-
-static unsigned* ntp_sched_slot(void* stream, int* slot) {
+static unsigned* ntp_sched_slot(void* stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
         vitk_set_error("gemm_nt: cannot query the current device");
@@ -1216,36 +1090,13 @@ static unsigned* ntp_sched_slot(void* stream, int* slot) {
         d.base = ptr;
     }
     for (int i = 0; i < d.used; ++i)
-        if (d.streams[i] == stream) {
-            if (slot) *slot = i;
-            return d.base + (size_t)i * 16;
-        }
+        if (d.streams[i] == stream) return d.base + (size_t)i * 16;
     if (d.used == NTP_SCHED_SLOTS) {
         vitk_set_error("gemm_nt: more than %d streams have launched GEMMs on device %d", NTP_SCHED_SLOTS, dev);
         return nullptr;
     }
     d.streams[d.used] = stream;
-    d.part[d.used] = nullptr;
-    if (slot) *slot = d.used;
     return d.base + (size_t)(d.used++) * 16;
-}
-
-// How the left-over tile round of a persistent launch is cut along K: 0 = not at all, else the number of parts per tile.  The
-// tiles beyond the last full round of `grid` workgroups keep only that many of them busy for a whole tile; cut into s parts of
-// nk / s K-steps they take a 1/s of that plus the exchange of the partial tiles (a 256 KB store per part, s - 1 such loads for the
-// part that finishes last: worth it for long K only).
-static int ntp_split(int num_tiles, int grid, int cus, int nk) {
-    // read per launch (two getenv calls), so that one process can time both settings on the same device
-    const char* off_s = getenv("VITK_NT_SPLITK");                        // 0: never; 2 / 3 / 4: at most that many parts
-    const int max_s = off_s ? atoi(off_s) : 0;          // off unless asked for: measured slower in the training step
-    const char* nk_s = getenv("VITK_NT_SPLITK_MIN_NK");
-    const int min_nk = nk_s && atoi(nk_s) > 0 ? atoi(nk_s) : 24;
-    if (max_s < 2 || grid != cus || (grid & 7) || grid > 2 * NTP_PART_TILES || nk < min_nk) return 0;
-    const int left = num_tiles % grid;
-    if (left == 0 || 2 * left > grid) return 0;
-    for (int s_ = max_s < 4 ? max_s : 4; s_ >= 2; --s_)
-        if (s_ * left <= grid && nk % s_ == 0 && nk / s_ >= 4) return s_;
-    return 0;
 }
 
 // compute units of the current device (cached per device id); <= 0 on failure
@@ -1328,9 +1179,8 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     const int cus = big ? vitk_num_cus() : 1;
     if (cus <= 0) { vitk_set_error("gemm_nt: cannot query the compute-unit count"); return VITK_ELAUNCH; }
     p.sched = nullptr;
-    int slot = 0;
     if (big) {
-        p.sched = ntp_sched_slot(stream, &slot);
+        p.sched = ntp_sched_slot(stream);
         if (p.sched == nullptr) return VITK_ELAUNCH;
     }
     const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_NT);       // every return below closes the bracket
@@ -1341,19 +1191,6 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
         p.cb = ntp_column_block(p.tiles_m, p.tiles_n, K, cus);
         const size_t smem = NTP_LDS;
         const int grid = p.num_tiles < cus ? p.num_tiles : cus;      // one persistent workgroup per CU
-        p.t_full = p.num_tasks = p.num_tiles;
-        p.split = 1; p.nkp = K / GBK; p.part_ws = nullptr; p.part_cnt = nullptr;
-        if (const int parts = ntp_split(p.num_tiles, grid, cus, K / GBK)) {
-            float* buf = ntp_part_buffer(slot, cus);
-            if (buf != nullptr) {                                     // without the buffer the round simply stays whole
-                const int left = p.num_tiles % grid;
-                p.split = parts; p.nkp = K / GBK / parts;
-                p.t_full = p.num_tiles - left;
-                p.num_tasks = p.t_full + parts * left;
-                p.part_cnt = reinterpret_cast<unsigned*>(buf);
-                p.part_ws = buf + 128;
-            }
-        }
 #define VITK_LAUNCH_BIG(E)                                                                                              \
     case E: {                                                                                                           \
         static VitkLdsOnce once = {};                                                                                   \
