@@ -16,7 +16,15 @@ bf16 = torch.bfloat16
 f32 = torch.float32
 
 
+# torch.cuda.current_stream() builds a Stream object behind several Python-level device look-ups (8 us a call, a seventh of the
+# host time of a launch-bound step); the raw handle of the current stream of the current device is one C call
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -154,9 +154,10 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise VitkError("FusedAdamW: parameters must be on the GPU")
                 st = self.state[p]
                 ops.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), **kw)
+        stamp = torch.tensor(float(self._steps))            # one tensor for every parameter's "step" entry
         for st in self.state.values():
             if "step" in st:
-                st["step"] = torch.tensor(float(self._steps))
+                st["step"] = stamp
         if model is not None and hasattr(model, "_refresh_transposes"):
             # bf16 copies were written by the kernel itself; the transposed ones go to the side stream (VITK_DEFER_WT=0: this stream)
             model._refresh_transposes(defer=os.environ.get("VITK_DEFER_WT", "1") != "0")
