@@ -8,6 +8,8 @@ test_kd.py:43-88.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -102,9 +104,26 @@ class StudentWithDistillation(nn.Module):
         self.teacher = teacher_model
 
     def forward(self, x):
-        student_logits = self.student(x)
-        if self.training and self.teacher is not None:
+        if not (self.training and self.teacher is not None):
+            return self.student(x)
+        # The two forward passes do not depend on each other.  Where the student has a side stream (the one its weight-gradient
+        # GEMMs use in backward, idle now), the teacher runs there: each model's GEMMs fill the compute units that the other's
+        # last tile rounds leave empty.  The teacher's activations are allocated under that stream, so its allocator pool
+        # hands them on in that stream's order; only the logits cross over, behind the event.
+        side = self.student._wgrad_stream() if (x.is_cuda and hasattr(self.student, "_wgrad_stream")
+                                                and os.environ.get("VITK_KD_OVERLAP", "1") != "0") else None
+        if side is None:
+            student_logits = self.student(x)
             with torch.no_grad():
                 teacher_logits = self.teacher(x)
             return student_logits, teacher_logits
-        return student_logits
+        ready = torch.cuda.Event()
+        ready.record()                                   # x is complete once everything queued so far has run
+        side.wait_event(ready)
+        with torch.cuda.stream(side), torch.no_grad():
+            teacher_logits = self.teacher(x)
+            done = torch.cuda.Event()
+            done.record(side)
+        student_logits = self.student(x)
+        torch.cuda.current_stream().wait_event(done)     # the loss reads the teacher's logits; x may be released after this
+        return student_logits, teacher_logits
