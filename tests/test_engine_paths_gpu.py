@@ -84,6 +84,42 @@ def test_kd_workload_matches_oracle(device, student, pool):
     assert all(p.grad is None for p in t.parameters())
 
 
+def test_side_stream_placements_change_no_bit(device, monkeypatch):
+    """Two things run on the side stream because nothing waits for them right away: the teacher's forward pass beside the
+    student's (VITK_KD_OVERLAP) and the refresh of the transposed weight copies after an optimizer step (VITK_DEFER_WT).  Three
+    distillation steps with both placements on and with both off must agree in every bit of the losses and of the weights -
+    a missing wait between the streams would show as a difference (or as a stale weight in the third step's gradients)."""
+    from vision_transformers_torch_xla_amd import optim_factory
+    from vision_transformers_torch_xla_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy, StudentWithDistillation
+    from vision_transformers_torch_xla_amd.vit import create_model
+    data = [_batch(6, 224, 40, 900 + i) for i in range(3)]
+
+    def run(flag):
+        monkeypatch.setenv("VITK_KD_OVERLAP", flag)
+        monkeypatch.setenv("VITK_DEFER_WT", flag)
+        torch.manual_seed(11)
+        s = create_model("deit_tiny_distilled_patch16_224", num_classes=40, global_pool="token", drop_path_rate=0.1, depth=3).to(device)
+        t = create_model("vit_small_patch16_224", num_classes=40, global_pool="avg", depth=2).to(device).eval()
+        for p in t.parameters():
+            p.requires_grad = False
+        model = StudentWithDistillation(s, t).train()
+        crit = DistillationLoss(LabelSmoothingCrossEntropy(0.1), 0.7, 4.0)
+        opt = optim_factory.create_optimizer(_Args, s)
+        losses = []
+        for x, y in data:
+            loss = crit(model(x.to(device)), y.to(device))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), s._flat["p"].detach().cpu().clone(), s._flat["b"].detach().cpu().clone()
+
+    on, off = run("1"), run("0")
+    for a, b in zip(on, off):
+        assert torch.equal(a, b)
+
+
 def test_kd_loss_gradient_matches_autograd(device):
     """the fused criterion on identical logits: value and d/d(student logits) against autograd through the oracle's formula"""
     from oracle import ref_ops as R
