@@ -108,6 +108,14 @@ int vitk_layernorm_bwd_gather(const void* dy, const void* x, const float* mean, 
                               const int* in_inv, const int* out_inv, float* dgamma, float* dbeta, int accumulate, int M,
                               int D, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The second half of any vitk_layernorm_bwd* call on its own.  Those calls sum dgamma / dbeta in two stages: per-block partial
+ * rows in the workspace, then a fixed-order reduction.  Called with dgamma = dbeta = NULL they stop after the first stage, and this
+ * entry point runs the second one later - on another stream if the caller orders it behind the first call (nothing inside a
+ * backward pass reads the LayerNorm parameter gradients, torch autograd only needs them at the optimizer step,
+ * engine.py:268-274) - from the same workspace, M and D.  Bit-identical to the one-call form. */
+int vitk_layernorm_bwd_reduce(const void* workspace, size_t workspace_bytes, int M, int D, float* dgamma, float* dbeta,
+                              int accumulate, void* stream);
+
 /* ---- GEMM, bf16 MFMA, fp32 accumulate.
  * vitk_gemm_nt: C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue.  Replaces nn.Linear forward/dgrad inside timm
  * Attention.qkv/.proj and Mlp.fc1/.fc2 (models/vision_transformer.py:149-159,164-171), the head (:618,990) and the

@@ -85,9 +85,10 @@ def test_kd_workload_matches_oracle(device, student, pool):
 
 
 def test_side_stream_placements_change_no_bit(device, monkeypatch):
-    """Two things run on the side stream because nothing waits for them right away: the teacher's forward pass beside the
-    student's (VITK_KD_OVERLAP) and the refresh of the transposed weight copies after an optimizer step (VITK_DEFER_WT).  Three
-    distillation steps with both placements on and with both off must agree in every bit of the losses and of the weights -
+    """Three things run on the side stream because nothing waits for them right away: the teacher's forward pass beside the
+    student's (VITK_KD_OVERLAP), the refresh of the transposed weight copies after an optimizer step (VITK_DEFER_WT) and the
+    second stage of the LayerNorm parameter gradients (VITK_DEFER_LN_REDUCE).  Three distillation steps with the placements
+    on and with all of them off must agree in every bit of the losses and of the weights -
     a missing wait between the streams would show as a difference (or as a stale weight in the third step's gradients)."""
     from vision_transformers_torch_xla_amd import optim_factory
     from vision_transformers_torch_xla_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy, StudentWithDistillation
@@ -97,6 +98,7 @@ def test_side_stream_placements_change_no_bit(device, monkeypatch):
     def run(flag):
         monkeypatch.setenv("VITK_KD_OVERLAP", flag)
         monkeypatch.setenv("VITK_DEFER_WT", flag)
+        monkeypatch.setenv("VITK_DEFER_LN_REDUCE", flag)
         torch.manual_seed(11)
         s = create_model("deit_tiny_distilled_patch16_224", num_classes=40, global_pool="token", drop_path_rate=0.1, depth=3).to(device)
         t = create_model("vit_small_patch16_224", num_classes=40, global_pool="avg", depth=2).to(device).eval()

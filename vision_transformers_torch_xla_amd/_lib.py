@@ -35,6 +35,7 @@ SIGNATURES = {
     "vitk_layernorm_fwd_gather": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _i, _p]),
     "vitk_layernorm_bwd_gather": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vitk_layernorm_bwd_workspace": (_sz, [_i, _i]),
+    "vitk_layernorm_bwd_reduce": (_i, [_p, _sz, _i, _i, _p, _p, _i, _p]),
     "vitk_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "vitk_layernorm_bwd_noalloc": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vitk_layernorm_bwd_scaled": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _sz, _p]),

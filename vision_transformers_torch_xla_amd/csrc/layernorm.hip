@@ -369,7 +369,8 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* mean, const f
                        void* dx, const float* rowscale, int rows_per_group, void* dxs, float* dgamma, float* dbeta, int accumulate,
                        int M, int D, void* workspace, size_t workspace_bytes, void* stream, const int* in_inv = nullptr,
                        const int* out_inv = nullptr) {
-    VITK_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
+    VITK_REQUIRE(dy && x && mean && rstd && gamma && dx && workspace, "layernorm_bwd: null pointer");
+    VITK_REQUIRE((dgamma != nullptr) == (dbeta != nullptr), "layernorm_bwd: dgamma and dbeta must both be given or both be null");
     VITK_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 1024, "layernorm_bwd: need M>0, D%%8==0, D<=1024 (M=%d D=%d)", M, D);
     VITK_REQUIRE(vitk_aligned(dy, 16) && vitk_aligned(x, 16) && vitk_aligned(dx, 16) && (!dres || vitk_aligned(dres, 16)),
                  "layernorm_bwd: pointers must be 16-byte aligned");
@@ -402,7 +403,21 @@ static int ln_bwd_impl(const void* dy, const void* x, const float* mean, const f
     if (pr) vitk_prof_end(stream);
     int rc = vitk_check_launch("layernorm_bwd");
     if (rc) return rc;
+    if (dgamma == nullptr) return 0;      // the partial rows stay in the workspace for vitk_layernorm_bwd_reduce
     ln_bwd_reduce_kernel<<<(2 * D + 15) / 16, 1024, 0, s>>>(partial, grid, D, dgamma, dbeta, accumulate);
+    return vitk_check_launch("layernorm_bwd_reduce");
+}
+
+int vitk_layernorm_bwd_reduce(const void* workspace, size_t workspace_bytes, int M, int D, float* dgamma, float* dbeta,
+                              int accumulate, void* stream) {
+    VITK_REQUIRE(workspace && dgamma && dbeta, "layernorm_bwd_reduce: null pointer");
+    VITK_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && D <= 1024, "layernorm_bwd_reduce: need M>0, D%%8==0, D<=1024 (M=%d D=%d)", M, D);
+    if (workspace_bytes < vitk_layernorm_bwd_workspace(M, D)) {
+        vitk_set_error("layernorm_bwd_reduce: workspace %zu < %zu", workspace_bytes, vitk_layernorm_bwd_workspace(M, D));
+        return VITK_ENOSPC;
+    }
+    ln_bwd_reduce_kernel<<<(2 * D + 15) / 16, 1024, 0, (hipStream_t)stream>>>((const float*)workspace, ln_bwd_grid(M), D, dgamma, dbeta,
+                                                                               accumulate);
     return vitk_check_launch("layernorm_bwd_reduce");
 }
 

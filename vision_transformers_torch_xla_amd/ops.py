@@ -80,18 +80,25 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, smap=None, rows_per_sample=0):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, accumulate=False, ws: Workspace = None, dx=None,
-                  rowscale=None, rows_per_group=0, in_inv=None, out_inv=None, out_rows=None):
+                  rowscale=None, rows_per_group=0, in_inv=None, out_inv=None, out_rows=None, partial_out=None):
     """Returns dx bf16 [M,D] (= LN backward of dy, plus dres when given); writes/accumulates dgamma, dbeta (fp32 [D]).
     With rowscale (fp32 [M / rows_per_group]) returns (dx, dx_scaled) where dx_scaled[row] = rowscale[group] * dx[row].
     in_inv (int32 [samples]): dy / mean / rstd are compact, in_inv[sample] = compact index or -1 (sample skipped the branch);
-    out_inv: dx_scaled is compact over the samples with out_inv >= 0 (out_rows rows)."""
+    out_inv: dx_scaled is compact over the samples with out_inv >= 0 (out_rows rows).
+    partial_out (a list): dgamma / dbeta are NOT written; their per-block partial sums go to a buffer of this call's own, which
+    is appended to the list for layernorm_bwd_reduce (the caller runs it later, e.g. on another stream)."""
     _chk(dy, bf16, "dy"); _chk(x, bf16, "x"); _chk(gamma, f32, "gamma"); _chk(dgamma, f32, "dgamma"); _chk(dbeta, f32, "dbeta")
     if dres is not None:
         _chk(dres, bf16, "dres")
     M, D = x.shape
     lib = _lib.load()
     need = lib.vitk_layernorm_bwd_workspace(M, D)
-    w = (ws or _default_ws).get(need, x.device)
+    if partial_out is not None:
+        w = torch.empty(max(int(need), 16), dtype=torch.uint8, device=x.device)
+        partial_out.append((w, M, D, dgamma, dbeta, bool(accumulate)))
+        dgamma = dbeta = None
+    else:
+        w = (ws or _default_ws).get(need, x.device)
     if dx is None:
         dx = torch.empty_like(x)
     dxs = None
@@ -114,6 +121,13 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, accumulate
     check(lib.vitk_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres), _ptr(dx), _ptr(dgamma),
                                  _ptr(dbeta), int(accumulate), M, D, _ptr(w), w.numel(), _stream()), "layernorm_bwd")
     return dx
+
+
+def layernorm_bwd_reduce(item):
+    """second stage of a layernorm_bwd call made with partial_out: item = (partial buffer, M, D, dgamma, dbeta, accumulate)"""
+    w, M, D, dgamma, dbeta, accumulate = item
+    check(_lib.load().vitk_layernorm_bwd_reduce(_ptr(w), w.numel(), M, D, _ptr(dgamma), _ptr(dbeta), int(accumulate), _stream()),
+          "layernorm_bwd_reduce")
 
 
 # ----------------------------------------------------------------------------------------------------- GEMM

@@ -733,8 +733,10 @@ class VisionTransformer(nn.Module):
                         kw.update(out_inv=nxt.inv, out_rows=nxt.nk * N)
             if "in_inv" in kw and "rows_per_group" not in kw:
                 kw["rows_per_group"] = N
+            # nothing inside backward reads a LayerNorm's parameter gradients: with a side stream only the first stage (per-block
+            # partial sums) runs here, the fixed-order reduction follows on the side stream with the next weight-gradient GEMM
             r = ops.layernorm_bwd(dy, xin, mean, rstd, norm.weight, g[gname + ".weight"], g[gname + ".bias"], dres=dres, accumulate=acc,
-                                  ws=ws, **kw)
+                                  ws=ws, partial_out=pending_ln if defer_ln else None, **kw)
             return r if isinstance(r, tuple) else (r, None)
 
         def branch_input_grad(dx_full, br, prepared):
@@ -755,6 +757,15 @@ class VisionTransformer(nn.Module):
         # host a step or more ahead of the GPU every step then allocates fresh memory.)
         side = self._wgrad_stream()
         held, lagging = [], None        # operands of the current block; (event, operands) of the block before
+        pending_ln = []                 # LayerNorm parameter-gradient reductions not yet handed to the side stream
+        defer_ln = side is not None and os.environ.get("VITK_DEFER_LN_REDUCE", "1") != "0"
+
+        def flush_ln():
+            """call with the side stream current and ordered behind the LayerNorm kernels that filled the partial buffers"""
+            for item in pending_ln:
+                ops.layernorm_bwd_reduce(item)
+                held.append(item[0])
+            pending_ln.clear()
 
         Hh, hd, hp = self.num_heads, self.head_dim, self._hd_pad
 
@@ -785,6 +796,7 @@ class VisionTransformer(nn.Module):
             ev.record()
             side.wait_event(ev)
             with torch.cuda.stream(side):
+                flush_ln()
                 wgrad_gemm(dy, xin, wname, bname, self._ws_side)
             held.append((dy, xin))
 
@@ -858,6 +870,12 @@ class VisionTransformer(nn.Module):
             if p.grad is None or p.grad.data_ptr() != self._gview[n].data_ptr():
                 p.grad = self._gview[n]
         self._grad_valid = True
+        if pending_ln:
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                flush_ln()
         report(self._total, True)
         ev = side_event()
         if ev is not None:
