@@ -66,6 +66,21 @@ def test_layernorm_fwd_bwd(device, M, D):
                                  rowscale=sc.to(device), rows_per_group=rpg)
     assert torch.equal(dx3, dx)
     assert torch.equal(dxs, ops.rowscale(dx, sc.to(device), rpg))
+    # two-call form: first stage only (partial sums in a buffer of the call's own), the reduction later - bit-identical, also
+    # when it accumulates
+    pending = []
+    dg3, db3 = torch.full((D,), 7.0, device=device), torch.full((D,), -3.0, device=device)
+    dx4 = ops.layernorm_bwd(dy.to(device), x.to(device), mean, rstd, gamma.to(device), dg3, db3, dres=dres.to(device), partial_out=pending)
+    assert torch.equal(dx4, dx) and len(pending) == 1
+    assert torch.all(dg3 == 7.0) and torch.all(db3 == -3.0)            # untouched until the second call
+    ops.layernorm_bwd_reduce(pending[0])
+    assert torch.equal(dg3, dg2) and torch.equal(db3, db2)
+    pending = []
+    ops.layernorm_bwd(dy.to(device), x.to(device), mean, rstd, gamma.to(device), dg3, db3, accumulate=True, partial_out=pending)
+    ops.layernorm_bwd_reduce(pending[0])
+    dg4, db4 = dg2.clone(), db2.clone()
+    ops.layernorm_bwd(dy.to(device), x.to(device), mean, rstd, gamma.to(device), dg4, db4, accumulate=True)
+    assert torch.equal(dg3, dg4) and torch.equal(db3, db4)
     assert torch.equal(dxs.cpu(), (dx.float().cpu() * sc.repeat_interleave(rpg)[:, None]).to(bf16))
 
 
