@@ -122,6 +122,46 @@ def test_side_stream_placements_change_no_bit(device, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("kd", [False, True])
+def test_graphed_step_is_the_eager_step(device, monkeypatch, kd):
+    """VITK_GRAPH_STEP=1: train_one_epoch captures forward + loss + backward in a HIP graph after two eager steps and replays it.
+    Seven steps (the last one a smaller batch, which runs eagerly) against the eager loop with stochastic depth computed for
+    every sample (VITK_DROPPATH_COMPACT=0, the arithmetic the replayable step uses): returned statistics and every weight bit
+    must be the same - with the per-step learning rate, the re-drawn DropPath factors and, for distillation, the teacher's
+    forward pass on the side stream inside the graph."""
+    from vision_transformers_torch_xla_amd import engine, optim_factory, utils
+    from vision_transformers_torch_xla_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy, StudentWithDistillation
+    from vision_transformers_torch_xla_amd.vit import create_model
+    monkeypatch.setenv("VITK_DROPPATH_COMPACT", "0")
+    data = [_batch(8, 224, 40, 700 + i) for i in range(6)] + [_batch(4, 224, 40, 777)]
+    lr = utils.cosine_scheduler(1e-3, 1e-5, 1, len(data), warmup_epochs=1, warmup_steps=2)
+
+    def run(flag):
+        monkeypatch.setenv("VITK_GRAPH_STEP", flag)
+        torch.manual_seed(5)
+        s = create_model("vit_tiny_patch16_224", num_classes=40, global_pool="avg", drop_path_rate=0.2, depth=3).to(device)
+        model, crit = s, LabelSmoothingCrossEntropy(0.1)
+        if kd:
+            t = create_model("vit_small_patch16_224", num_classes=40, global_pool="avg", depth=2).to(device).eval()
+            for p in t.parameters():
+                p.requires_grad = False
+            model, crit = StudentWithDistillation(s, t), DistillationLoss(crit, 0.7, 4.0)
+        opt = optim_factory.create_optimizer(_Args, s)
+        stats = engine.train_one_epoch(model, crit, data, opt, device, 0, None, 1.0, None, None, lr_schedule_values=lr,
+                                       num_training_steps_per_epoch=len(data), update_freq=1, log_freq=1)
+        torch.cuda.synchronize()
+        assert s._static_drop is None                     # the loop leaves the model in its per-step mode
+        return stats, s._flat["p"].detach().cpu().clone()
+
+    before = engine.GraphedStep.total_replays
+    st_g, p_g = run("1")
+    assert engine.GraphedStep.total_replays - before == 4      # steps 2-5: two eager steps first, the smaller last batch eager
+    st_e, p_e = run("0")
+    assert engine.GraphedStep.total_replays - before == 4
+    assert st_g == st_e
+    assert torch.equal(p_g, p_e)
+
+
 def test_kd_loss_gradient_matches_autograd(device):
     """the fused criterion on identical logits: value and d/d(student logits) against autograd through the oracle's formula"""
     from oracle import ref_ops as R

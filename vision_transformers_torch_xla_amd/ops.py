@@ -305,11 +305,15 @@ def copy_samples(src, dst, sample_list, elems_per_sample):
     return dst
 
 
-def copy_from_pinned(src, device):
-    """device copy of a pinned host tensor, made by a kernel that reads the host memory (no hipMemcpyAsync call)"""
+def copy_from_pinned(src, device, out=None):
+    """device copy of a pinned host tensor, made by a kernel that reads the host memory (no hipMemcpyAsync call); `out`: an
+    existing device tensor of the same size to copy into"""
     if src.is_cuda or not src.is_pinned() or not src.is_contiguous():
         raise _lib.VitkError("copy_from_pinned: expected a contiguous pinned host tensor")
-    dst = torch.empty(src.shape, dtype=src.dtype, device=device)
+    if out is not None:
+        if not out.is_cuda or not out.is_contiguous() or out.numel() * out.element_size() != src.numel() * src.element_size():
+            raise _lib.VitkError("copy_from_pinned: out must be a contiguous device tensor of the source's size")
+    dst = out if out is not None else torch.empty(src.shape, dtype=src.dtype, device=device)
     check(_lib.load().vitk_copy_from_host(src.data_ptr(), _ptr(dst), src.numel() * src.element_size(), _stream()), "copy_from_host")
     return dst
 

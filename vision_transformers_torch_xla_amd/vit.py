@@ -273,6 +273,7 @@ class VisionTransformer(nn.Module):
         self._branch_samples = [0, 0, 0, 0]  # samples a residual branch was computed for / could have been (benchmark accounting)
         self._bwd_taps = None                # tests: dict that receives per-layer intermediate gradients
         self._grad_ready_hook = None         # data-parallel reducer: called with the flat offset below which grads are final
+        self._static_drop = None             # stochastic depth from tables at fixed device addresses (a captured step replays them)
         self._ws = ops.Workspace()
         self._flat = None
         if weight_init != "skip":
@@ -490,7 +491,8 @@ class VisionTransformer(nn.Module):
         if self._wt_ready is not None:           # a transposition still queued on the side stream writes the same copies
             cur.wait_event(self._wt_ready)
             self._wt_ready = None
-        side = self._wgrad_stream() if defer else None
+        # (a captured step that is replayed does not see events recorded outside its graph: no deferral then)
+        side = self._wgrad_stream() if (defer and self._static_drop is None) else None
         if side is None:
             ops.transpose_bf16_batched(self._wt_plan)
             return
@@ -534,6 +536,46 @@ class VisionTransformer(nn.Module):
             st[2] += plans[2 * k + 1].nk if plans[2 * k + 1].compact else B
         return out
 
+    # -- stochastic depth for a step that is captured in a HIP graph and replayed
+    def begin_static_droppath(self, B, device):
+        """From now on training forwards of batch size B read their per-sample DropPath factors from ONE device table at a fixed
+        address instead of drawing them: launch shapes no longer depend on the draws (every branch is computed for every sample
+        and scaled, timm's own arithmetic), so a captured forward + backward can be replayed.  The caller draws new factors with
+        refresh_static_droppath() before every step, the first included (one torch.rand per step, exactly as the per-step path
+        draws, so both see the same random stream).  end_static_droppath() returns to per-step draws."""
+        rates = [blk.drop_path for blk in self.blocks]
+        active = [i for i, r in enumerate(rates) if r > 0.0]
+        table = torch.zeros(max(2 * len(active) * B, 4), dtype=f32, device=device)
+        scales = [(None, None)] * self.depth
+        for k, i in enumerate(active):
+            pair = []
+            for j in range(2):
+                b = _Branch()
+                b.scale, b.nk, b.compact = table[(2 * k + j) * B:(2 * k + j + 1) * B], B, False
+                b.kept = b.dropped = b.inv = b.scale_c = None
+                pair.append(b)
+            scales[i] = tuple(pair)
+        self._static_drop = dict(B=B, table=table, scales=scales, keep=torch.tensor([1.0 - rates[i] for i in active for _ in range(2)], dtype=f32))
+
+    def refresh_static_droppath(self):
+        """new Bernoulli(keep) / keep factors for every residual branch, written into the static table by one copy kernel (the
+        draws come from torch's CPU generator, as in the per-step path)"""
+        sd = self._static_drop
+        keep, B = sd["keep"], sd["B"]
+        if keep.numel() == 0:
+            return
+        mask = torch.rand(len(keep), B) < keep[:, None]
+        _, flts = self._pin_ring.next(max(len(keep) * B, 4))
+        flts[:len(keep) * B].view(len(keep), B).copy_(mask.to(f32) / keep[:, None])
+        if sd["table"].is_cuda and flts.is_pinned() and (len(keep) * B) % 4 == 0:
+            ops.copy_from_pinned(flts, sd["table"].device, out=sd["table"])
+        else:
+            sd["table"].copy_(flts[:sd["table"].numel()], non_blocking=True)
+        self._pin_ring.copied()
+
+    def end_static_droppath(self):
+        self._static_drop = None
+
     def forward(self, x: torch.Tensor):
         if not x.is_cuda:
             raise VitkError("VisionTransformer.forward: input must be a GPU tensor; this model has no CPU implementation")
@@ -542,7 +584,10 @@ class VisionTransformer(nn.Module):
         if x.dtype != f32 or not x.is_contiguous():
             x = x.float().contiguous()
         self._sync_weights()
-        scales = self._draw_drop_scales(x.shape[0], x.device)
+        if self._static_drop is not None and self.training and self._static_drop["B"] == x.shape[0]:
+            scales = self._static_drop["scales"]         # refreshed by refresh_static_droppath(), never drawn in here
+        else:
+            scales = self._draw_drop_scales(x.shape[0], x.device)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist):
             return _ViTFunction.apply(x, self, scales, *self._plist)
         outs, _ = self._forward_impl(x, scales, save=False)
