@@ -16,6 +16,7 @@ overlapped with backward (dp.py) in place of xm.optimizer_step (:185).
 from __future__ import annotations
 
 import math
+import os
 import sys
 from typing import Iterable, Optional
 
@@ -67,7 +68,6 @@ class GraphedStep:
 
     @staticmethod
     def wanted(model, update_freq):
-        import os
         return (os.environ.get("VITK_GRAPH_STEP") == "1" and update_freq == 1 and getattr(model, "reducer", None) is None
                 and hasattr(_core_model(model), "begin_static_droppath"))
 
@@ -131,60 +131,62 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     optimizer.zero_grad()
     graphed = GraphedStep(model, criterion) if GraphedStep.wanted(model, update_freq) else None      # VITK_GRAPH_STEP=1
 
-    for data_iter_step, (samples, targets) in enumerate(data_loader):
-        step = data_iter_step // update_freq
-        if num_training_steps_per_epoch is not None and step >= num_training_steps_per_epoch:
-            continue
-        it = start_steps + step
-        if (lr_schedule_values is not None or wd_schedule_values is not None) and data_iter_step % update_freq == 0:
-            for param_group in optimizer.param_groups:
-                if lr_schedule_values is not None:
-                    param_group["lr"] = lr_schedule_values[it] * param_group.get("lr_scale", 1.0)
-                if wd_schedule_values is not None and param_group.get("weight_decay", None) is not None:
-                    param_group["weight_decay"] = wd_schedule_values[it]
+    try:
+        for data_iter_step, (samples, targets) in enumerate(data_loader):
+            step = data_iter_step // update_freq
+            if num_training_steps_per_epoch is not None and step >= num_training_steps_per_epoch:
+                continue
+            it = start_steps + step
+            if (lr_schedule_values is not None or wd_schedule_values is not None) and data_iter_step % update_freq == 0:
+                for param_group in optimizer.param_groups:
+                    if lr_schedule_values is not None:
+                        param_group["lr"] = lr_schedule_values[it] * param_group.get("lr_scale", 1.0)
+                    if wd_schedule_values is not None and param_group.get("weight_decay", None) is not None:
+                        param_group["weight_decay"] = wd_schedule_values[it]
 
-        if mixup_fn is not None:
-            samples, targets = mixup_fn(samples, targets)
-        samples = samples.to(device, non_blocking=True)
-        targets = targets.to(device, non_blocking=True)
+            if mixup_fn is not None:
+                samples, targets = mixup_fn(samples, targets)
+            samples = samples.to(device, non_blocking=True)
+            targets = targets.to(device, non_blocking=True)
 
-        last_micro = (data_iter_step + 1) % update_freq == 0
-        if reducer is not None:
-            reducer.enabled = last_micro          # gradient accumulation: only the last micro-step communicates
-        if graphed is not None:
-            output, loss = graphed.step(samples, targets)
-        else:
-            output = model(samples)
-            loss = criterion(output, targets)
-            if update_freq > 1:
-                loss = loss / update_freq
-            loss.backward()
-        if last_micro:
+            last_micro = (data_iter_step + 1) % update_freq == 0
             if reducer is not None:
-                reducer.wait()
-            if max_norm is not None and max_norm > 0:
-                clip_grad_norm_(model, max_norm)
-            optimizer.step()
-            optimizer.zero_grad()
-            if model_ema is not None:
-                model_ema.update(model)
+                reducer.enabled = last_micro          # gradient accumulation: only the last micro-step communicates
+            if graphed is not None:
+                output, loss = graphed.step(samples, targets)
+            else:
+                output = model(samples)
+                loss = criterion(output, targets)
+                if update_freq > 1:
+                    loss = loss / update_freq
+                loss.backward()
+            if last_micro:
+                if reducer is not None:
+                    reducer.wait()
+                if max_norm is not None and max_norm > 0:
+                    clip_grad_norm_(model, max_norm)
+                optimizer.step()
+                optimizer.zero_grad()
+                if model_ema is not None:
+                    model_ema.update(model)
 
-        class_acc = None
-        if mixup_fn is None:
-            out0 = output[0] if isinstance(output, tuple) else output
-            class_acc = (ops.argmax_rows(out0.detach().float()) == targets).float().mean()
+            class_acc = None
+            if mixup_fn is None:
+                out0 = output[0] if isinstance(output, tuple) else output
+                class_acc = (ops.argmax_rows(out0.detach().float()) == targets).float().mean()
 
-        if data_iter_step % log_freq == 0 or data_iter_step < 5:
-            metric_logger.update(loss=loss.detach())
-            if class_acc is not None:
-                metric_logger.meters["class_acc"].update(class_acc, n=samples.size(0))
-            metric_logger.update(lr=optimizer.param_groups[0]["lr"])
-        if log_writer is not None:          # a per-step host log is the caller's choice: it costs one sync per step
-            lv = metric_logger.meters["loss"].value if metric_logger.meters["loss"].count else float("nan")
-            log_writer.update(loss=lv, lr=optimizer.param_groups[0]["lr"])
+            if data_iter_step % log_freq == 0 or data_iter_step < 5:
+                metric_logger.update(loss=loss.detach())
+                if class_acc is not None:
+                    metric_logger.meters["class_acc"].update(class_acc, n=samples.size(0))
+                metric_logger.update(lr=optimizer.param_groups[0]["lr"])
+            if log_writer is not None:          # a per-step host log is the caller's choice: it costs one sync per step
+                lv = metric_logger.meters["loss"].value if metric_logger.meters["loss"].count else float("nan")
+                log_writer.update(loss=lv, lr=optimizer.param_groups[0]["lr"])
 
-    if graphed is not None:
-        graphed.close()
+    finally:
+        if graphed is not None:       # also when the loop raises: the model must not keep reading the static DropPath table
+            graphed.close()
     metric_logger.flush()
     if "loss" in metric_logger.meters and not math.isfinite(metric_logger.meters["loss"].global_avg):
         print("Loss is {}, stopping training".format(metric_logger.meters["loss"].global_avg))
