@@ -75,7 +75,7 @@ def train_macs_per_image(model):
     return fixed, attn, mlp, L
 
 
-def _cpu_steps(name, batch, steps, threads):
+def _cpu_steps(name, batch, steps, warm):
     from oracle import ref_engine, ref_ops
     from oracle.ref_vit import create_ref_model
     torch.manual_seed(0)
@@ -85,21 +85,59 @@ def _cpu_steps(name, batch, steps, threads):
     x = torch.randn(batch, 3, 224, 224, generator=g)
     y = torch.randint(0, 1000, (batch,), generator=g)
     crit = lambda o, t: ref_ops.label_smoothing_ce(o, t, 0.1)
-    ref_engine.ref_train_one_epoch(model, crit, [(x, y)], opt)                      # warm-up
+    ref_engine.ref_train_one_epoch(model, crit, [(x, y)] * warm, opt)               # warm-up
     t0 = time.time()
     ref_engine.ref_train_one_epoch(model, crit, [(x, y)] * steps, opt)
     return batch * steps / (time.time() - t0)
 
 
-def cpu_baseline(batch=32, steps=3, threads=None):
-    """The oracle's reference-semantics fp32 train step (engine.py:257-274 restated) on this box's host cores: the headline
-    model on a bounded sample, and the reference's own CPU-runnable case (ViT-Tiny/16, 64 images per step) beside it."""
-    threads = threads or min(16, os.cpu_count() or 1)
+def host_cpu():
+    """(model string, physical cores of the machine, logical CPUs of the machine, CPUs this process may use)"""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid)); pid = cid = None
+        if pid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    return model, len(phys) or None, os.cpu_count() or 1, usable
+
+
+def cpu_baseline():
+    """The oracle's reference-semantics fp32 train step (engine.py:257-274 restated) on this box's host cores: the headline model at
+    the reference's batch of 64 on a bounded sample, and the reference's own CPU-runnable case (ViT-Tiny/16, 64 images per step)
+    beside it.  Threads: every CPU this job may use - the scheduler's share of the machine (OMP_NUM_THREADS where the box sets
+    it, else the affinity mask), which on a shared GPU host is fewer than the machine's physical cores; both counts and the CPU
+    model are in the record."""
+    model, phys, logical, usable = host_cpu()
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        share = 0
+    threads = max(1, min(usable, share) if share > 0 else min(usable, phys or usable))
     torch.set_num_threads(threads)
-    out = {"value": _cpu_steps("vit_base_patch16_224", batch, steps, threads), "unit": "images/s", "cores": threads, "kind": "port",
-           "sample": f"ViT-B/16 224px fp32 CPU oracle train step (fwd+bwd+AdamW), batch {batch}, {steps} timed steps after 1 warm-up"}
-    out["vit_tiny_batch64"] = {"value": _cpu_steps("vit_tiny_patch16_224", 64, 3, threads), "unit": "images/s",
-                               "sample": "ViT-Tiny/16 224px fp32, batch 64, 3 timed steps after 1 warm-up (the reference's CPU-runnable configuration)"}
+    # ViT-B at 64 images is about 6 s per step on 16 threads: 3 warm-up + 10 timed steps would be 75 s of a run that has to finish
+    # in minutes, so the sample is cut to 1 warm-up + 3 timed steps (192 images); ViT-Tiny runs the full 3 + 10
+    out = {"value": _cpu_steps("vit_base_patch16_224", 64, 3, 1), "unit": "images/s", "cores": threads, "kind": "port",
+           "cpu_model": model, "machine_physical_cores": phys, "machine_logical_cpus": logical, "cpus_usable_by_this_job": usable,
+           "sample": "ViT-B/16 224px fp32 CPU oracle train step (fwd+bwd+AdamW), batch 64, 3 timed steps after 1 warm-up (cut from 10 after 3: 6 s per step)"}
+    out["vit_tiny_batch64"] = {"value": _cpu_steps("vit_tiny_patch16_224", 64, 10, 3), "unit": "images/s",
+                               "sample": "ViT-Tiny/16 224px fp32, batch 64, 10 timed steps after 3 warm-up (the reference's CPU-runnable configuration)"}
     return out
 
 
@@ -214,6 +252,9 @@ def main():
 
     run(args.warmup, 0)
     core._branch_samples[:] = [0, 0, 0, 0]
+    reducer = getattr(model, "reducer", None)
+    if reducer is not None:
+        reducer.timing = True                                   # timed events around every collective of the timed region
     want_roof = not args.no_roofline and args.prof_every > 0
     if want_roof:
         ops.prof_reset()
@@ -223,11 +264,25 @@ def main():
     t0 = time.perf_counter()
     stats = run(args.steps, args.warmup, args.prof_every if want_roof else 0)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if want_roof:
         ops.prof_enable(False)
+    # every rank's own view of the timed region: its step time (its own clock, taken before the closing barrier) and the time its
+    # gradient all-reduces spent between "inputs ready" and "done" on the reducer's stream (transfer + waiting for the slowest
+    # peer); gathered on rank 0 so that one record shows whether a bad scaling number is one slow rank or the collectives
+    per_rank = None
+    if reducer is not None:
+        comm_ms, comm_n, comm_elems = reducer.comm_ms()
+        mine = torch.tensor([rank, own_elapsed / args.steps * 1e3, comm_ms / args.steps, comm_n / args.steps, comm_elems * 4.0 / args.steps],
+                            dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        rows = [torch.zeros_like(mine) for _ in range(n_ranks)]
+        dist.all_gather(rows, mine)
+        per_rank = [{"rank": int(r[0]), "ms_per_step": round(float(r[1]), 3), "allreduce_ms_per_step": round(float(r[2]), 3),
+                     "allreduce_share_of_step": round(float(r[2]) / max(float(r[1]), 1e-9), 4), "collectives_per_step": round(float(r[3]), 2),
+                     "allreduce_bytes_per_step": int(r[4])} for r in rows]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -258,6 +313,9 @@ def main():
             "step_tflops_per_gpu_executed": round(flop_img_exec * args.batch / (ms * 1e-3) / 1e12, 1),
             "gflop_per_image": {"algorithmic": round(flop_img / 1e9, 2), "executed": round(flop_img_exec / 1e9, 2)},
         }
+        if per_rank is not None:
+            # the all-reduces run on a side stream under the backward kernels: their share is not a share of the critical path
+            result["per_rank"] = per_rank
         if want_roof:
             nt_ms, nt_fl, nt_n = ops.prof_read(ops.PROF_GEMM_NT)
             tn_ms, tn_fl, tn_n = ops.prof_read(ops.PROF_GEMM_TN)

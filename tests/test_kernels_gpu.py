@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.util import REL_TOL, bf16_excess, rb, rel_l2
+from tests.util import REL_TOL, bf16_excess, fp32_anchor, rb, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -45,12 +45,14 @@ def test_layernorm_fwd_bwd(device, M, D):
     y, mean, rstd = ops.layernorm_fwd(x.to(device), gamma.to(device), beta.to(device), 1e-6)
     assert rel_l2(y.float(), rb(yr)) <= REL_TOL
     assert bf16_excess(y, yr) <= 1.0
+    fp32_anchor(f"kernel.layernorm.fwd[{M}x{D}]", rel_l2(y.float(), yr))
     assert rel_l2(mean, x.float().mean(-1)) <= 1e-5 or M == 1
     dgamma = torch.zeros(D, device=device)
     dbeta = torch.zeros(D, device=device)
     dx = ops.layernorm_bwd(dy.to(device), x.to(device), mean, rstd, gamma.to(device), dgamma, dbeta, dres=dres.to(device))
     ref_dx = xr.grad + dres.float()
     assert rel_l2(dx.float(), rb(ref_dx)) <= REL_TOL
+    fp32_anchor(f"kernel.layernorm.bwd.dx[{M}x{D}]", rel_l2(dx.float(), ref_dx))
     assert rel_l2(dgamma, gr.grad) <= REL_TOL
     assert rel_l2(dbeta, br.grad) <= REL_TOL
     # accumulate=True adds to the existing gradient, no dres
@@ -141,6 +143,8 @@ def test_gemm_nt_epilogues(device, M, N, K):
     assert rel_l2(c.float(), rb(ref)) <= REL_TOL
     c = ops.gemm_nt(a.to(device), b.to(device), epilogue=_lib.EPI_BIAS_RES, bias=bias.to(device), res=res.to(device))
     assert rel_l2(c.float(), rb(res.float() + acc)) <= REL_TOL
+    tag = f"[{M}x{N}x{K}]"
+    fp32_anchor("kernel.gemm_nt.bias_res" + tag, rel_l2(c.float(), res.float() + acc))
     # dgelu: out = (a b^T) * gelu'(aux)
     aux = _randb((M, N), g)
     auxr = aux.float().requires_grad_(True)
@@ -155,8 +159,12 @@ def test_gemm_nt_epilogues(device, M, N, K):
     dg = ops.gemm_nt(a.to(device), b.to(device), epilogue=_lib.EPI_BIAS_GELU_DG, bias=bias.to(device), out2=out2b)
     assert rel_l2(out2b.float(), rb(F.gelu(acc))) <= REL_TOL
     assert rel_l2(dg.float(), rb(R.dgelu(acc))) <= REL_TOL
+    fp32_anchor("kernel.gemm_nt.gelu_dg.act" + tag, rel_l2(out2b.float(), F.gelu(acc)))
+    fp32_anchor("kernel.gemm_nt.gelu_dg.derivative" + tag, rel_l2(dg.float(), R.dgelu(acc)))
     c = ops.gemm_nt(a.to(device), b.to(device), epilogue=_lib.EPI_MUL, aux=dg)
     assert rel_l2(c.float(), rb((a.double() @ b.double().t()).float() * dg.float().cpu())) <= REL_TOL
+    # the chain fc1 epilogue -> multiply epilogue against exact math: (a b^T) * gelu'(a b^T + bias), nothing rounded
+    fp32_anchor("kernel.gemm_nt.mul_by_kept_derivative" + tag, rel_l2(c.float(), (a.double() @ b.double().t()).float() * R.dgelu(acc)))
     # in-place residual (out aliases res), as the model uses it
     resd = res.to(device).clone()
     ops.gemm_nt(a.to(device), b.to(device), epilogue=_lib.EPI_BIAS_RES, bias=bias.to(device), res=resd, out=resd)
@@ -216,6 +224,64 @@ def test_gemm_nt_concurrent_streams(device):
     torch.cuda.synchronize()
     for o1, o2 in outs:
         assert torch.equal(o1, want1) and torch.equal(o2, want2)
+
+
+def test_gemm_nt_dirty_tile_counters_are_reported(device):
+    """The persistent kernel expects its stream's tile counters zeroed.  A counter word dirtied by hand makes the next launch skip
+    tiles - and report it: the call after that refuses to launch and names the cause until the counters are reset."""
+    from vision_transformers_torch_xla_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    a, b = _randb((256 * 300, 128), g).to(device), _randb((256, 128), g, 0.05).to(device)     # 300 tiles: every residue claims
+    want = ops.gemm_nt(a, b)
+    torch.cuda.synchronize()
+    ops.gemm_nt_sched_poke(3, 5)                 # five claims that nobody made on the counter of blockIdx % 8 == 3
+    ops.gemm_nt(a, b)                            # launches (the host cannot know), skips tiles, reports
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.VitkError, match="tile counters"):
+        ops.gemm_nt(a, b)
+    with pytest.raises(_lib.VitkError, match="tile counters"):          # sticky
+        ops.gemm_nt(a, b)
+    ops.gemm_nt_sched_reset()
+    assert torch.equal(ops.gemm_nt(a, b), want)
+    # an arrival ticket left behind (a launch that died after some workgroups had entered) is caught by the last one to enter
+    ops.gemm_nt_sched_poke(0, 0x01000001)
+    ops.gemm_nt(a, b)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.VitkError, match="tile counters"):
+        ops.gemm_nt(a, b)
+    ops.gemm_nt_sched_reset()
+    assert torch.equal(ops.gemm_nt(a, b), want)
+    # many streams: more than the library has counter sets; the least recently used set is recycled
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    for s_ in streams:
+        with torch.cuda.stream(s_):
+            assert torch.equal(ops.gemm_nt(a, b), want)
+    torch.cuda.synchronize()
+
+
+def test_gemm_nt_capped_grid(tmp_path):
+    """VITK_GEMM_CUS below 8 (or not a multiple of 8) would leave tiles unclaimed - claim c of residue x is tile G + 8 c + x - so
+    the cap is rounded to a multiple of 8, at least 8.  Read once per process: run in a child."""
+    import subprocess
+    import sys
+    code = (
+        "import torch\n"
+        "from vision_transformers_torch_xla_amd import ops\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "a = torch.randn(256 * 21 + 9, 192, generator=g).bfloat16().cuda(); b = (torch.randn(520, 192, generator=g) * 0.05).bfloat16().cuda()\n"
+        "got = ops.gemm_nt(a, b).float().cpu()\n"
+        "want = (a.float().cpu().double() @ b.float().cpu().double().t()).float().bfloat16().float()\n"
+        "err = ((got - want).norm() / want.norm()).item()\n"
+        "assert err < 1e-3, err\n"
+        "print('ok', err)\n")
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for cap in ("4", "12", "20"):
+        import os
+        env = dict(os.environ, VITK_GEMM_CUS=cap, PYTHONPATH=str(root))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (cap, r.stdout, r.stderr)
 
 
 def test_gemm_nt_shape_sweep(device):
@@ -324,6 +390,7 @@ def test_attention_fwd_bwd(device, B, N, H):
     out, lse = ops.attention_fwd(qkv.reshape(B * N, 3 * D).to(device), B, N, H, scale)
     assert rel_l2(out.float().reshape(B, N, D), res[True][0]) <= REL_TOL
     assert rel_l2(out.float().reshape(B, N, D), res[False][0]) <= 6e-3      # vs exact math: bf16 noise floor
+    fp32_anchor(f"kernel.attention.fwd[{B}x{N}x{H}]", rel_l2(out.float().reshape(B, N, D), res[False][0]))
     # lse against the definition
     qh, kh, _ = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     ref_lse = torch.logsumexp(qh @ kh.transpose(-1, -2) * scale, dim=-1)
@@ -341,6 +408,7 @@ def test_attention_fwd_bwd(device, B, N, H):
             continue
         errs[name] = rel_l2(got[..., sl], rb(want[..., sl]))
         assert rel_l2(got[..., sl], res[False][1][..., sl]) <= 1e-2, name
+        fp32_anchor(f"kernel.attention.bwd.d{name}[{B}x{N}x{H}]", rel_l2(got[..., sl], res[False][1][..., sl]))
     print(f"attention backward B={B} N={N} H={H}: " + ", ".join(f"d{k} {v:.1e}" for k, v in errs.items()))
     assert max(errs.values()) <= REL_TOL, errs
 

@@ -17,7 +17,7 @@ Two bars.
 import pytest
 import torch
 
-from tests.util import REL_TOL, rb, rel_l2
+from tests.util import REL_TOL, fp32_anchor, rb, rel_l2
 
 E2E_TOL = 1.5e-2
 E2E_GRAD_TOL = 3e-2
@@ -130,6 +130,25 @@ def test_forward_stagewise_identical_inputs(device, compact):
     print("forward stage-wise rel errors:", {k: f"{v:.1e}" for k, v in errs.items()})
     bad = {k: v for k, v in errs.items() if v > REL_TOL}
     assert not bad, bad
+    # the same stages against exact math (nothing rounded on the oracle's side), from the HIP stage's own inputs: what one
+    # stage adds to the distance from the fp32 oracle
+    with torch.no_grad():
+        li = 1
+        (xi, m1, r1, y1, qkv, o, lse, x2, m2, r2, y2, h, a, s1, s2) = saved["layers"][li]
+        blk = ref.blocks[li]
+        k1 = s1.kept.cpu().long() if s1.compact else torch.arange(B)
+        k2 = s2.kept.cpu().long() if s2.compact else torch.arange(B)
+        X, X2 = cpu(xi).reshape(B, N, D), cpu(x2).reshape(B, N, D)
+        Y1, QKV, O = [cpu(t).reshape(len(k1), N, -1) for t in (y1, qkv, o)]
+        Y2, Hh, A = [cpu(t).reshape(len(k2), N, -1) for t in (y2, h, a)]
+        pre_act = Y2 @ wq(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias
+        exact = {"ln1": (Y1, R.layernorm(X[k1], blk.norm1.weight, blk.norm1.bias)),
+                 "qkv": (QKV, Y1 @ wq(blk.attn.qkv.weight).t() + blk.attn.qkv.bias),
+                 "attn": (O, R.attention(QKV, H, emulate=False)),
+                 "ln2": (Y2, R.layernorm(X2[k2], blk.norm2.weight, blk.norm2.bias)),
+                 "fc1.dgelu": (Hh, R.dgelu(pre_act)), "gelu": (A, R.gelu(pre_act))}
+        for k, (got_, want_) in exact.items():
+            fp32_anchor(f"stage.fwd.{k}[compact={compact}]", rel_l2(got_, want_))
 
 
 @pytest.mark.parametrize("compact", [True, False])
@@ -171,6 +190,20 @@ def test_backward_stagewise_identical_inputs(device, compact):
         errs[f"{li}.attn.dx"] = rel_l2(cpu(tp["dx"]), rb(xi.grad))
         for n in ("attn.proj.weight", "attn.proj.bias", "attn.qkv.weight", "attn.qkv.bias", "norm1.weight", "norm1.bias"):
             errs[f"{li}.{n}"] = rel_l2(m._gview[f"blocks.{li}.{n}"], dict(blk.named_parameters())[n].grad)
+    # the same half-blocks through the fp32 oracle (no rounding anywhere), same inputs and cotangents
+    for li in range(m.depth):
+        tp = m._bwd_taps[li]
+        blk = ref.blocks[li]
+        ref.zero_grad()
+        x2 = cpu(tp["x2"]).requires_grad_(True)
+        ref.mlp_half(blk, x2, scales[li][1], False).backward(cpu(tp["dx_in"]))
+        fp32_anchor(f"stage.bwd.{li}.mlp.dx[compact={compact}]", rel_l2(cpu(tp["dx2"]), x2.grad))
+        fp32_anchor(f"stage.bwd.{li}.mlp.fc1.weight[compact={compact}]", rel_l2(m._gview[f"blocks.{li}.mlp.fc1.weight"], blk.mlp.fc1.weight.grad))
+        ref.zero_grad()
+        xi = cpu(tp["x"]).requires_grad_(True)
+        ref.attn_half(blk, xi, scales[li][0], False).backward(cpu(tp["dx2"]))
+        fp32_anchor(f"stage.bwd.{li}.attn.dx[compact={compact}]", rel_l2(cpu(tp["dx"]), xi.grad))
+        fp32_anchor(f"stage.bwd.{li}.attn.qkv.weight[compact={compact}]", rel_l2(m._gview[f"blocks.{li}.attn.qkv.weight"], blk.attn.qkv.weight.grad))
     m._bwd_taps = None
     print("backward stage-wise rel errors:", {k: f"{v:.1e}" for k, v in errs.items()})
     bad = {k: v for k, v in errs.items() if v > REL_TOL}
@@ -190,6 +223,7 @@ def test_forward_end_to_end(device, name, pool):
     e_emu, e_f32, floor = rel_l2(got, want_emu), rel_l2(got, want_f32), rel_l2(want_emu, want_f32)
     print(f"forward {name}/{pool}: vs emulated oracle {e_emu:.2e}, vs fp32 oracle {e_f32:.2e}; oracle emulated-vs-fp32 {floor:.2e}")
     assert e_emu <= E2E_TOL and e_f32 <= E2E_TOL
+    fp32_anchor(f"e2e.forward.{name}.{pool}", e_f32)
     # bit-exact index work on identical logits
     from vision_transformers_torch_xla_amd import ops
     assert torch.equal(ops.argmax_rows(got).cpu(), got.cpu().max(-1)[-1])

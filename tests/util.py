@@ -29,3 +29,47 @@ def bf16_excess(a: torch.Tensor, ref: torch.Tensor, atol: float = 1e-5) -> float
 
 def rb(x):
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The independent anchor.  The bf16-emulating oracle states the kernels' own rounding policy, so a commit that moves a
+# rounding point moves the kernel and that oracle together.  The fp32 oracle (emulate=False, exact math) does not move:
+# tests/golden/fp32_distance.json holds, per comparison, the distance to it that was measured when the file was last
+# recorded, and a later run may not exceed 1.25 x that value.  Recording: run the GPU suite with
+# VITK_RECORD_FP32_DISTANCE=<file> and commit the file as tests/golden/fp32_distance.json (the diff of that file then
+# shows, entry by entry, what a change did to the distance from exact math).
+import json as _json
+import os as _os
+from pathlib import Path as _Path
+
+FP32_ANCHOR_FILE = _Path(__file__).resolve().parent / "golden" / "fp32_distance.json"
+FP32_ANCHOR_SLACK = 1.25
+_anchor_cache = {}
+
+
+def _anchor_table():
+    if "t" not in _anchor_cache:
+        _anchor_cache["t"] = _json.loads(FP32_ANCHOR_FILE.read_text()) if FP32_ANCHOR_FILE.exists() else {}
+    return _anchor_cache["t"]
+
+
+def fp32_anchor(name: str, value: float, floor: float = 1e-7) -> float:
+    """`value` = a measured relative distance between a HIP result and the fp32 (non-emulating) oracle for comparison `name`.
+    Check mode (default): it must not exceed FP32_ANCHOR_SLACK x the recorded value (+ floor, for distances that are
+    rounding residue of exact results).  Record mode (VITK_RECORD_FP32_DISTANCE=<file>): the value is written to that file."""
+    value = float(value)
+    rec = _os.environ.get("VITK_RECORD_FP32_DISTANCE")
+    if rec:
+        path = _Path(rec)
+        table = _json.loads(path.read_text()) if path.exists() else {}
+        table[name] = float(f"{value:.4e}")
+        path.parent.mkdir(parents=True, exist_ok=True)
+        tmp = path.with_suffix(".tmp")
+        tmp.write_text(_json.dumps(table, indent=1, sort_keys=True) + "\n")
+        tmp.replace(path)
+        return value
+    table = _anchor_table()
+    assert name in table, f"no recorded fp32-oracle distance for {name!r}: record tests/golden/fp32_distance.json (see tests/util.py)"
+    bound = FP32_ANCHOR_SLACK * table[name] + floor
+    assert value <= bound, f"{name}: distance to the fp32 oracle {value:.3e} exceeds {FP32_ANCHOR_SLACK} x recorded {table[name]:.3e}"
+    return value

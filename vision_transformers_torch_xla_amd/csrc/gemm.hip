@@ -45,7 +45,27 @@ struct GemmNTParams {
     int tiles_m; int cb;          // persistent kernel: row tiles; column tiles per block of the tile order (cb = tiles_n: row-major)
     const int* smap; int rps;     // BIAS_RES only: output / residual row of GEMM row m is smap[m / rps] * rps + m % rps
     unsigned* sched;              // persistent kernel: this launch's tile counters, [8] per XCD + [8] = workgroups that have left
+    unsigned* sched_err;          // persistent kernel: sticky error word (host memory mapped into the device), null: no reporting
 };
+
+// Tile counters of the persistent kernels.  Word x (0..7) of a counter set belongs to the workgroups with blockIdx % 8 == x: its
+// low 24 bits count the claims made so far, its top byte the workgroups that have entered the kernel (the entry atomic adds
+// NTP_ARRIVE + 1: arrival ticket and first claim in one operation).  A set must be all zero when a launch starts; the kernel
+// cannot see that directly (other workgroups of the same launch may have been there first), but two things it can see: a
+// workgroup whose ticket is 0 must find no claims, and no ticket may reach the number of workgroups the launch has on that
+// counter - a set left dirty by a launch that never finished, or shared with a launch that runs at the same time (a captured
+// graph replayed on another stream than the one it was captured on), breaks one of them in some workgroup.  That workgroup
+// writes the sticky error word; the next GEMM call on the host refuses to launch and reports it.
+#define NTP_ARRIVE 0x01000000u
+#define NTP_CLAIM_MASK 0x00ffffffu
+static __device__ __forceinline__ void ntp_check_entry(const GemmNTParams& p, unsigned first, int xcd, int G) {
+    const unsigned arrivals = first >> 24, claims = first & NTP_CLAIM_MASK;
+    const unsigned wgs = (unsigned)((G - xcd + 7) >> 3);
+    const int later = p.num_tiles - G - xcd + 7;
+    const unsigned limit = wgs + (later > 0 ? (unsigned)(later >> 3) : 0u);
+    if ((arrivals >= wgs || (arrivals == 0u && claims != 0u) || claims >= limit) && p.sched_err != nullptr)
+        __hip_atomic_store(p.sched_err, 0x80000000u | ((unsigned)xcd << 24) | claims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Remap so that every XCD works on a
 // contiguous range of logical tiles (neighbouring tiles share the A row panel); bijective for any grid size.
@@ -417,12 +437,13 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
     typedef __attribute__((address_space(3))) unsigned lds_u32;
     lds_u32* mailbox = (lds_u32*)(__UINTPTR_TYPE__)(lds_base + (unsigned)(4 * LTILE * sizeof(bf16_t)));   // first word of wave 0's epilogue staging
     unsigned claim = 0;
-    auto issue_claim = [&]() {
-        if (wave == 0 && lane == 0) claim = atomicAdd(&p.sched[xcd], 1u);
+    auto issue_claim = [&](unsigned inc) {
+        if (wave == 0 && lane == 0) claim = atomicAdd(&p.sched[xcd], inc);
     };
+    bool entry = true;      // the claim in flight is the entry atomic: ticket + first claim, checked where it is first used
     int v = blockIdx.x, vn = 0;
     int m0, n0, nm0 = 0, nn0 = 0;
-    issue_claim();
+    issue_claim(NTP_ARRIVE + 1u);
     aim(v, m0, n0);
     stageA(0, 0);
     stageB(0, 0);
@@ -477,7 +498,11 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
             if (kt == 0 && loose) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTP_DRAIN) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (kt == 0) {
-                if (wave == 0 && lane == 0) *mailbox = (unsigned)G + 8u * claim + (unsigned)xcd;
+                if (wave == 0 && lane == 0) {
+                    if (entry) ntp_check_entry(p, claim, xcd, G);
+                    *mailbox = (unsigned)G + 8u * (claim & NTP_CLAIM_MASK) + (unsigned)xcd;
+                }
+                entry = false;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
@@ -505,7 +530,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         }
 
         if (pend_k >= 0) { stageB(pend_k, pend_par); pend_k = -1; }      // before the stores: vmcnt counts in issue order
-        if (has_next) issue_claim();                                      // likewise: the claim is older than every store
+        if (has_next) issue_claim(1u);                                    // likewise: the claim is older than every store
         // Epilogue.  The MFMA layout (lane = row lr, 4 columns) would store 32-byte pieces of 16 rows per instruction, and
         // the store path is paid per lane-access, not per byte.  Transpose through this wave's private 4 KB of LDS instead
         // (fp32, so the arithmetic is unchanged): 16 rows x 64 columns at a time, read back as lane = (row lane/8, 8
@@ -1063,22 +1088,28 @@ static TnPlan tn_plan(int M, int N, int K) {
     return q;
 }
 
-// Tile counters of the persistent NT kernel: one set of 16 words per (device, stream) - launches of one stream run one after the
-// other and the kernel leaves its set zeroed, launches of different streams may overlap and must not share one.  In host code the
-// array's name is only a stand-in: its device address comes from hipGetSymbolAddress, once per device.
+// Tile counters of the persistent NT kernels: one set of 16 words per (device, stream) - launches of one stream run one after the
+// other and a kernel leaves its set zeroed, launches of different streams may overlap and must not share one.  In host code the
+// array's name is only a stand-in: its device address comes from hipGetSymbolAddress, once per device.  A process that has used
+// more streams than there are sets recycles the set whose stream launched a GEMM longest ago (a finished launch leaves it clean).
+// A graph that captured a GEMM holds its capture stream's set: replay it on that stream, or at least never beside eager GEMMs of
+// that stream.
 #define NTP_SCHED_SLOTS 256
 static __device__ __align__(256) unsigned ntp_sched[NTP_SCHED_SLOTS * 16];
-struct NtpSchedDev { unsigned* base = nullptr; int used = 0; void* streams[NTP_SCHED_SLOTS]; };
+struct NtpSchedDev { unsigned* base = nullptr; unsigned* err_dev = nullptr; int used = 0; void* streams[NTP_SCHED_SLOTS]; unsigned long long tick[NTP_SCHED_SLOTS]; };
 static std::mutex g_ntp_sched_mu;
 static NtpSchedDev g_ntp_sched[64];
+static unsigned long long g_ntp_tick = 0;
+// the sticky error word of ntp_check_entry: one page of ordinary host memory, page-locked and mapped into every device once
+alignas(4096) static unsigned g_ntp_err_host[1024];
+static int g_ntp_err_state = 0;       // 0: not registered yet, 1: registered, -1: registration failed (no reporting)
 
-static unsigned* ntp_sched_slot(void* stream) {
+static NtpSchedDev* ntp_sched_dev() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
         vitk_set_error("gemm_nt: cannot query the current device");
         return nullptr;
     }
-    std::lock_guard<std::mutex> lk(g_ntp_sched_mu);
     NtpSchedDev& d = g_ntp_sched[dev];
     if (d.base == nullptr) {
         unsigned* ptr = nullptr;
@@ -1088,15 +1119,48 @@ static unsigned* ntp_sched_slot(void* stream) {
             return nullptr;
         }
         d.base = ptr;
+        if (g_ntp_err_state == 0)
+            g_ntp_err_state = hipHostRegister(g_ntp_err_host, sizeof(g_ntp_err_host), hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess ? 1 : -1;
+        void* dp = nullptr;
+        if (g_ntp_err_state == 1 && hipHostGetDevicePointer(&dp, g_ntp_err_host, 0) == hipSuccess) d.err_dev = (unsigned*)dp;
+        (void)hipGetLastError();      // a failed registration only switches the reporting off
     }
-    for (int i = 0; i < d.used; ++i)
-        if (d.streams[i] == stream) return d.base + (size_t)i * 16;
-    if (d.used == NTP_SCHED_SLOTS) {
-        vitk_set_error("gemm_nt: more than %d streams have launched GEMMs on device %d", NTP_SCHED_SLOTS, dev);
-        return nullptr;
+    return &d;
+}
+
+// the counter set of `stream` on the current device (recycling the least recently used one when all are taken); *slot_index: its number
+static unsigned* ntp_sched_slot(void* stream, unsigned** err_dev, int* slot_index = nullptr) {
+    std::lock_guard<std::mutex> lk(g_ntp_sched_mu);
+    NtpSchedDev* d = ntp_sched_dev();
+    if (d == nullptr) return nullptr;
+    if (err_dev) *err_dev = d->err_dev;
+    int at = -1;
+    for (int i = 0; i < d->used; ++i)
+        if (d->streams[i] == stream) { at = i; break; }
+    if (at < 0) {
+        if (d->used < NTP_SCHED_SLOTS) {
+            at = d->used++;
+        } else {
+            at = 0;
+            for (int i = 1; i < NTP_SCHED_SLOTS; ++i)
+                if (d->tick[i] < d->tick[at]) at = i;
+        }
+        d->streams[at] = stream;
     }
-    d.streams[d.used] = stream;
-    return d.base + (size_t)(d.used++) * 16;
+    d->tick[at] = ++g_ntp_tick;
+    if (slot_index) *slot_index = at;
+    return d->base + (size_t)at * 16;
+}
+
+// 0, or VITK_ELAUNCH with the error text set when a kernel has reported counters that were not zero at its start
+static int ntp_sched_check() {
+    const unsigned code = __atomic_load_n(&g_ntp_err_host[0], __ATOMIC_RELAXED);
+    if (code == 0) return 0;
+    vitk_set_error("gemm_nt: the tile counters of a stream were not zero when a GEMM started (workgroup residue %u saw %u claims): "
+                   "an earlier launch on that stream did not finish, or a captured graph is replayed beside launches of its capture "
+                   "stream; results of that GEMM are invalid.  vitk_gemm_nt_sched_reset() clears the state",
+                   (code >> 24) & 7u, code & 0xffffffu);
+    return VITK_ELAUNCH;
 }
 
 // compute units of the current device (cached per device id); <= 0 on failure
@@ -1107,10 +1171,12 @@ static int vitk_num_cus() {
     if (cache[dev] == 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return -1;
-        cache[dev] = n & ~7;      // a multiple of 8 keeps a workgroup's tiles on one XCD's share of the tile order
+        // A multiple of 8, and at least 8: claim c of residue x is tile G + 8 c + x, so a grid that does not hold every residue
+        // would leave tiles unclaimed (a device with fewer than 8 compute units takes the 128 x 128 kernel: see gemm_nt_impl)
+        cache[dev] = n & ~7;
         if (cache[dev] == 0) cache[dev] = n;
         const char* cap_s = getenv("VITK_GEMM_CUS");
-        if (cap_s && atoi(cap_s) > 0 && atoi(cap_s) < cache[dev]) cache[dev] = atoi(cap_s);
+        if (cap_s && atoi(cap_s) > 0 && atoi(cap_s) < cache[dev]) cache[dev] = atoi(cap_s) >= 8 ? atoi(cap_s) & ~7 : 8;
     }
     return cache[dev];
 }
@@ -1175,12 +1241,15 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     // handles K tails (zero fill) and small shapes.  VITK_GEMM_SMALL=1 forces the latter (A/B testing).
     static const bool force_small = getenv("VITK_GEMM_SMALL") != nullptr;
     const bool ld8 = ldc % 8 == 0 && (!res || ldres % 8 == 0) && (!out2 || ldout2 % 8 == 0) && (!aux || ldaux % 8 == 0);   // 16-byte row pieces
-    const bool big = !force_small && K % GBK == 0 && K >= 2 * GBK && M >= 512 && N >= 128 && N % 8 == 0 && ld8;
+    bool big = !force_small && K % GBK == 0 && K >= 2 * GBK && M >= 512 && N >= 128 && N % 8 == 0 && ld8;
     const int cus = big ? vitk_num_cus() : 1;
     if (cus <= 0) { vitk_set_error("gemm_nt: cannot query the compute-unit count"); return VITK_ELAUNCH; }
+    if (cus < 8 || (long long)((M + LBM - 1) / LBM) * ((N + LBN - 1) / LBN) / 8 >= (long long)NTP_CLAIM_MASK - 64) big = false;
     p.sched = nullptr;
+    p.sched_err = nullptr;
     if (big) {
-        p.sched = ntp_sched_slot(stream);
+        if (int rc_ = ntp_sched_check()) return rc_;
+        p.sched = ntp_sched_slot(stream, &p.sched_err);
         if (p.sched == nullptr) return VITK_ELAUNCH;
     }
     const bool pr = vitk_prof_begin(stream, 2.0 * (double)M * (double)N * (double)K, VITK_PROF_GEMM_NT);       // every return below closes the bracket
@@ -1245,6 +1314,25 @@ int vitk_gemm_nt_res_scatter(const void* A, int lda, const void* B, int ldb, voi
                  "gemm_nt_res_scatter: sample_map and rows_per_sample dividing M are required (M=%d rows_per_sample=%d)", M, rows_per_sample);
     return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, VITK_EPI_BIAS_RES, bias, res, ldres, rowscale, rows_per_group, nullptr, 0, nullptr,
                         0, nullptr, 0, 0, sample_map, rows_per_sample, stream);
+}
+
+int vitk_gemm_nt_sched_reset(void* stream) {
+    unsigned* err = nullptr;
+    unsigned* slot = ntp_sched_slot(stream, &err);
+    if (slot == nullptr) return VITK_ELAUNCH;
+    const hipError_t e = hipMemsetAsync(slot, 0, 16 * sizeof(unsigned), (hipStream_t)stream);
+    if (e != hipSuccess) { vitk_set_error("gemm_nt_sched_reset: %s", hipGetErrorString(e)); return VITK_ELAUNCH; }
+    __atomic_store_n(&g_ntp_err_host[0], 0u, __ATOMIC_RELAXED);
+    return VITK_OK;
+}
+
+int vitk_gemm_nt_sched_poke(void* stream, int word, unsigned value) {
+    VITK_REQUIRE(word >= 0 && word < 16, "gemm_nt_sched_poke: word %d outside the 16-word counter set", word);
+    unsigned* slot = ntp_sched_slot(stream, nullptr);
+    if (slot == nullptr) return VITK_ELAUNCH;
+    const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)(slot + word), (int)value, 1, (hipStream_t)stream);
+    if (e != hipSuccess) { vitk_set_error("gemm_nt_sched_poke: %s", hipGetErrorString(e)); return VITK_ELAUNCH; }
+    return VITK_OK;
 }
 
 size_t vitk_gemm_tn_workspace(int M, int N, int K) {

@@ -42,6 +42,8 @@ class GradReducer:
         self._after = None        # latest event of a stream other than the current one that also writes gradients
         self.launched = []        # (start, end) slices reduced in the last backward, for tests / introspection
         self._new_pass = True     # the next report starts a new backward pass
+        self.timing = False       # bracket every collective with timed events on the reducer's stream (diagnostics, see comm_ms)
+        self._timed = []          # (start event, end event, elements) of the collectives launched while `timing` was on
 
     def _side_stream(self, device):
         if self._stream is None or self._stream.device != device:
@@ -97,6 +99,9 @@ class GradReducer:
             if self._after is not None:
                 side.wait_event(self._after)
             with torch.cuda.stream(side):
+                if self.timing:
+                    t_start = torch.cuda.Event(enable_timing=True)
+                    t_start.record(side)
                 if native_avg:
                     dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.pg)
                 else:
@@ -107,8 +112,10 @@ class GradReducer:
                     host.mul_(1.0 / self.world)
                     dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg)
                     g.copy_(host)
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=self.timing)
                 done.record(side)
+                if self.timing:
+                    self._timed.append((t_start, done, b - a))
             self._events.append(done)
         else:
             g.mul_(1.0 / self.world)
@@ -123,6 +130,20 @@ class GradReducer:
             for ev in self._events:
                 cur.wait_event(ev)
             self._events = []
+
+    def comm_ms(self, reset=True):
+        """(milliseconds, collectives, elements) of the collectives launched while `timing` was on: the time between each
+        collective's start on the reducer's stream (its inputs ready) and its end - transfer time plus the wait for the slowest
+        peer.  Synchronises with the reducer's stream."""
+        total, n, elems = 0.0, 0, 0
+        for t0, t1, cnt in self._timed:
+            t1.synchronize()
+            total += t0.elapsed_time(t1)
+            n += 1
+            elems += cnt
+        if reset:
+            self._timed = []
+        return total, n, elems
 
     def wait(self):
         """Make the current stream (or the host, for CPU tensors) wait for every outstanding bucket.  Backward already does

@@ -164,6 +164,16 @@ def gemm_nt(a, b, *, epilogue=EPI_PLAIN, bias=None, out=None, out_dtype=bf16, re
     return out
 
 
+def gemm_nt_sched_reset():
+    """zero the persistent GEMM's tile counters of the current stream (in stream order) and clear a reported violation"""
+    check(_lib.load().vitk_gemm_nt_sched_reset(_stream()), "gemm_nt_sched_reset")
+
+
+def gemm_nt_sched_poke(word: int, value: int):
+    """tests: write one of the 16 counter words of the current stream"""
+    check(_lib.load().vitk_gemm_nt_sched_poke(_stream(), int(word), int(value)), "gemm_nt_sched_poke")
+
+
 def gemm_tn(a, b, out, *, dbias=None, accumulate=False, ws: Workspace = None):
     """out[N,K] (fp32) (+)= a[M,N]^T @ b[M,K]; optionally dbias[N] (+)= column sums of a."""
     for t, n in ((a, "a"), (b, "b")):
