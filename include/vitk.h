@@ -139,10 +139,13 @@ int vitk_gemm_nt_res_scatter(const void* A, int lda, const void* B, int ldb, voi
  * leaves them zeroed, and checks at its start that it found them so (a launch that never finished, or a captured graph replayed
  * beside launches of its capture stream, leaves or makes them dirty).  A violation is sticky: every later vitk_gemm_nt call
  * returns VITK_ELAUNCH and names it, until vitk_gemm_nt_sched_reset(stream) zeroes that stream's counters (in stream order) and
- * clears the state.  vitk_gemm_nt_sched_poke writes one of the 16 counter words of the stream (tests of that check).  No
+ * clears the state.  vitk_gemm_nt_sched_poke writes one of the 16 counter words of the stream, vitk_gemm_nt_sched_state reads them (tests of that check).  No
  * counterpart in the reference: library-internal state of kernels that stand in for torch's addmm (models/vision_transformer.py:149-171). */
 int vitk_gemm_nt_sched_reset(void* stream);
 int vitk_gemm_nt_sched_poke(void* stream, int word, unsigned value);
+/* synchronises with the stream and copies its 16 counter words out (all zero between launches); *reporting: 0 = the kernels cannot
+ * report (no host page could be mapped), 1 / 2 = they can.  Returns 1 while a violation is recorded, 0 otherwise, < 0 on error. */
+int vitk_gemm_nt_sched_state(void* stream, unsigned* words16, int* reporting);
 size_t vitk_gemm_tn_workspace(int M, int N, int K);
 int vitk_gemm_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                  float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream);

@@ -234,10 +234,13 @@ def test_gemm_nt_dirty_tile_counters_are_reported(device):
     g = torch.Generator().manual_seed(12)
     a, b = _randb((256 * 300, 128), g).to(device), _randb((256, 128), g, 0.05).to(device)     # 300 tiles: every residue claims
     want = ops.gemm_nt(a, b)
-    torch.cuda.synchronize()
+    words, reporting, bad = ops.gemm_nt_sched_state()
+    assert words == [0] * 16 and reporting in (1, 2) and not bad, (words, reporting, bad)     # a finished launch leaves them zeroed
     ops.gemm_nt_sched_poke(3, 5)                 # five claims that nobody made on the counter of blockIdx % 8 == 3
+    assert ops.gemm_nt_sched_state()[0][3] == 5
     ops.gemm_nt(a, b)                            # launches (the host cannot know), skips tiles, reports
-    torch.cuda.synchronize()
+    words, reporting, bad = ops.gemm_nt_sched_state()
+    assert bad, (words, reporting)
     with pytest.raises(_lib.VitkError, match="tile counters"):
         ops.gemm_nt(a, b)
     with pytest.raises(_lib.VitkError, match="tile counters"):          # sticky

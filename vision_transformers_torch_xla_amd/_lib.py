@@ -43,6 +43,7 @@ SIGNATURES = {
     "vitk_gemm_nt_res_scatter": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p]),
     "vitk_gemm_nt_sched_reset": (_i, [_p]),
     "vitk_gemm_nt_sched_poke": (_i, [_p, _i, C.c_uint]),
+    "vitk_gemm_nt_sched_state": (_i, [_p, C.POINTER(C.c_uint), C.POINTER(_i)]),
     "vitk_gemm_tn_workspace": (_sz, [_i, _i, _i]),
     "vitk_gemm_tn": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _sz, _p]),
     "vitk_attention_fwd": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),

@@ -1100,9 +1100,12 @@ struct NtpSchedDev { unsigned* base = nullptr; unsigned* err_dev = nullptr; int 
 static std::mutex g_ntp_sched_mu;
 static NtpSchedDev g_ntp_sched[64];
 static unsigned long long g_ntp_tick = 0;
-// the sticky error word of ntp_check_entry: one page of ordinary host memory, page-locked and mapped into every device once
-alignas(4096) static unsigned g_ntp_err_host[1024];
-static int g_ntp_err_state = 0;       // 0: not registered yet, 1: registered, -1: registration failed (no reporting)
+// the sticky error word of ntp_check_entry: host memory that the devices write directly - one page of the library's own data,
+// page-locked and mapped once (no allocation); where the driver refuses to register that page, a page of pinned memory from
+// hipHostMalloc, once per process
+alignas(4096) static unsigned g_ntp_err_page[1024];
+static unsigned* g_ntp_err_host = g_ntp_err_page;
+static int g_ntp_err_state = 0;       // 0: not set up yet, 1: registered page, 2: hipHostMalloc page, -1: neither (no reporting)
 
 static NtpSchedDev* ntp_sched_dev() {
     int dev = 0;
@@ -1119,11 +1122,23 @@ static NtpSchedDev* ntp_sched_dev() {
             return nullptr;
         }
         d.base = ptr;
-        if (g_ntp_err_state == 0)
-            g_ntp_err_state = hipHostRegister(g_ntp_err_host, sizeof(g_ntp_err_host), hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess ? 1 : -1;
+        if (g_ntp_err_state == 0) {
+            if (hipHostRegister(g_ntp_err_page, sizeof(g_ntp_err_page), hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
+                g_ntp_err_state = 1;
+            } else {
+                void* hp = nullptr;
+                if (hipHostMalloc(&hp, 4096, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hp != nullptr) {
+                    g_ntp_err_host = (unsigned*)hp;
+                    g_ntp_err_host[0] = 0u;
+                    g_ntp_err_state = 2;
+                } else {
+                    g_ntp_err_state = -1;
+                }
+            }
+        }
         void* dp = nullptr;
-        if (g_ntp_err_state == 1 && hipHostGetDevicePointer(&dp, g_ntp_err_host, 0) == hipSuccess) d.err_dev = (unsigned*)dp;
-        (void)hipGetLastError();      // a failed registration only switches the reporting off
+        if (g_ntp_err_state > 0 && hipHostGetDevicePointer(&dp, g_ntp_err_host, 0) == hipSuccess) d.err_dev = (unsigned*)dp;
+        (void)hipGetLastError();      // a failed set-up only switches the reporting off
     }
     return &d;
 }
@@ -1324,6 +1339,19 @@ int vitk_gemm_nt_sched_reset(void* stream) {
     if (e != hipSuccess) { vitk_set_error("gemm_nt_sched_reset: %s", hipGetErrorString(e)); return VITK_ELAUNCH; }
     __atomic_store_n(&g_ntp_err_host[0], 0u, __ATOMIC_RELAXED);
     return VITK_OK;
+}
+
+int vitk_gemm_nt_sched_state(void* stream, unsigned* words16, int* reporting) {
+    unsigned* err = nullptr;
+    unsigned* slot = ntp_sched_slot(stream, &err);
+    if (slot == nullptr) return VITK_ELAUNCH;
+    if (reporting) *reporting = err != nullptr ? g_ntp_err_state : 0;
+    if (words16) {
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemcpy(words16, slot, 16 * sizeof(unsigned), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { vitk_set_error("gemm_nt_sched_state: %s", hipGetErrorString(e)); return VITK_ELAUNCH; }
+    }
+    return (int)__atomic_load_n(&g_ntp_err_host[0], __ATOMIC_RELAXED) != 0 ? 1 : VITK_OK;
 }
 
 int vitk_gemm_nt_sched_poke(void* stream, int word, unsigned value) {

@@ -169,6 +169,17 @@ def gemm_nt_sched_reset():
     check(_lib.load().vitk_gemm_nt_sched_reset(_stream()), "gemm_nt_sched_reset")
 
 
+def gemm_nt_sched_state():
+    """(the 16 counter words of the current stream after synchronising with it, reporting mode, violation recorded)"""
+    import ctypes
+    words = (ctypes.c_uint * 16)()
+    rep = ctypes.c_int(0)
+    rc = _lib.load().vitk_gemm_nt_sched_state(_stream(), words, ctypes.byref(rep))
+    if rc < 0:
+        check(rc, "gemm_nt_sched_state")
+    return list(words), rep.value, bool(rc)
+
+
 def gemm_nt_sched_poke(word: int, value: int):
     """tests: write one of the 16 counter words of the current stream"""
     check(_lib.load().vitk_gemm_nt_sched_poke(_stream(), int(word), int(value)), "gemm_nt_sched_poke")
