@@ -287,6 +287,52 @@ def test_gemm_nt_capped_grid(tmp_path):
         assert r.returncode == 0 and "ok" in r.stdout, (cap, r.stdout, r.stderr)
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 40, 768, 768), (256 * 700 + 77, 768, 768), (50432, 1024, 1024), (197 * 300, 2304, 768),
+                                   (197 * 290 + 5, 520, 3072), (256 * 9, 256, 2304)])
+def test_gemm_nt_four_wave_kernel_is_bit_identical(device, monkeypatch, M, N, K):
+    """gemm_ntq_kernel (four waves, output stores and side-operand loads deferred under the neighbouring tiles' MFMAs) against
+    gemm_ntp_kernel (eight waves, VITK_GEMM_NTQ=0): the same fp32 accumulation order and the same epilogue arithmetic on fp32 values,
+    so every epilogue it takes must agree bit for bit - full and ragged tiles, one tile per workgroup and many (the deferred path),
+    stochastic-depth row maps with sample boundaries inside a wave's rows, in-place residual, two launches in a row."""
+    from vision_transformers_torch_xla_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = _randb((M, K), g).to(device), _randb((N, K), g, 0.05).to(device)
+    bias = (torch.randn(N, generator=g) * 0.1).to(device)
+    side = _randb((M, N), g).to(device)
+    per = 197 if M % 197 == 0 else (256 if M % 256 == 0 else M)
+    kept = M // per
+    samples = kept + 3
+    smap = torch.randperm(samples, generator=g)[:kept].sort().values.to(torch.int32).to(device)
+    rs = (torch.rand(kept, generator=g) + 0.5).to(device)
+    stream = _randb((samples * per, N), g).to(device)
+
+    def run():
+        outs = [ops.gemm_nt(a, b), ops.gemm_nt(a, b, epilogue=_lib.EPI_BIAS, bias=bias),
+                ops.gemm_nt(a, b, epilogue=_lib.EPI_BIAS_RES, bias=bias, res=side),
+                ops.gemm_nt(a, b, epilogue=_lib.EPI_MUL, aux=side)]
+        if per >= 128:
+            outs.append(ops.gemm_nt(a, b, epilogue=_lib.EPI_BIAS_RES, bias=bias, res=side, rowscale=rs, rows_per_group=per))
+            x = stream.clone()
+            ops.gemm_nt(a, b, epilogue=_lib.EPI_BIAS_RES, bias=bias, res=x, out=x, rowscale=rs, rows_per_group=per, smap=smap, rows_per_sample=per)
+            outs.append(x)
+        inplace = side.clone()
+        ops.gemm_nt(a, b, epilogue=_lib.EPI_BIAS_RES, bias=bias, res=inplace, out=inplace)
+        outs.append(inplace)
+        outs.append(ops.gemm_nt(a, b))           # a second launch on counters the first one left
+        torch.cuda.synchronize()
+        return outs
+
+    monkeypatch.setenv("VITK_GEMM_NTQ", "0")
+    want = run()
+    monkeypatch.setenv("VITK_GEMM_NTQ", "1")
+    got = run()
+    for i, (w, g_) in enumerate(zip(want, got)):
+        assert torch.equal(w, g_), (i, (w.float() - g_.float()).abs().max().item())
+    ref = rb((a.float().cpu().double() @ b.float().cpu().double().t()).float())
+    assert rel_l2(got[0].float(), ref) <= REL_TOL
+
+
 def test_gemm_nt_shape_sweep(device):
     """Persistent-kernel shapes chosen at random (seeded): ragged M and N, tile counts below, around and far above the
     compute-unit count (so some workgroups claim no second tile, some many), K from two steps up; plain and residual epilogues"""

@@ -12,7 +12,7 @@ def main(names):
     names = names or [p.stem for p in sorted(CSRC.glob("*.hip"))]
     for n in names:
         src = CSRC / f"{n}.hip"
-        extra = {"gemm": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "attention": ["-fno-slp-vectorize"]}.get(n, [])      # as build.py's EXTRA_FLAGS
+        extra = {"gemm": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "gemm_ntq": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "attention": ["-fno-slp-vectorize"]}.get(n, [])      # as build.py's EXTRA_FLAGS
         r = subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", *extra, "-c", str(src), "-o", "/dev/null",
                             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
         cur = {}

@@ -14,13 +14,14 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libvitk.so"
-SOURCES = ["api.hip", "layernorm.hip", "gemm.hip", "attention.hip", "elementwise.hip", "loss.hip", "optim.hip", "preprocess.hip"]
-HEADERS = [CSRC / "common.h", CSRC.parent.parent / "include" / "vitk.h"]
+SOURCES = ["api.hip", "layernorm.hip", "gemm.hip", "gemm_ntq.hip", "attention.hip", "elementwise.hip", "loss.hip", "optim.hip", "preprocess.hip"]
+HEADERS = [CSRC / "common.h", CSRC / "gemm_nt.h", CSRC.parent.parent / "include" / "vitk.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-inline-asm", "-Wno-cuda-compat", "-Wno-pass-failed"]
 # gemm.hip: the tile claim of the persistent kernel is ONE lane's atomic whose result is used a whole tile later; hipcc's atomic
 # optimizer would turn it into a wave-wide reduction and wait for the result on the spot
 EXTRA_FLAGS = {"gemm.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+               "gemm_ntq.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
                # beside MFMAs a packed fp32 instruction costs more issue time than the two scalar ones it replaces; the
                # softmax arithmetic between the attention products is faster left unpacked (forward -2 %, backward -1..3 %)
                "attention.hip": ["-fno-slp-vectorize"]}
