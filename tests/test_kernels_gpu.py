@@ -291,7 +291,7 @@ def test_gemm_nt_capped_grid(tmp_path):
                                    (197 * 290 + 5, 520, 3072), (256 * 9, 256, 2304)])
 def test_gemm_nt_four_wave_kernel_is_bit_identical(device, monkeypatch, M, N, K):
     """gemm_ntq_kernel (four waves, output stores and side-operand loads deferred under the neighbouring tiles' MFMAs) against
-    gemm_ntp_kernel (eight waves, VITK_GEMM_NTQ=0): the same fp32 accumulation order and the same epilogue arithmetic on fp32 values,
+    gemm_ntp_kernel (eight waves, the default; the four-wave kernel runs with VITK_GEMM_NTQ=1 only): the same fp32 accumulation order and the same epilogue arithmetic on fp32 values,
     so every epilogue it takes must agree bit for bit - full and ragged tiles, one tile per workgroup and many (the deferred path),
     stochastic-depth row maps with sample boundaries inside a wave's rows, in-place residual, two launches in a row."""
     from vision_transformers_torch_xla_amd import _lib

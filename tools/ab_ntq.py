@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The four-wave deferred-epilogue NT kernel (gemm_ntq_kernel) against the eight-wave one (gemm_ntp_kernel, VITK_GEMM_NTQ=0) on the
+"""The four-wave deferred-epilogue NT kernel (gemm_ntq_kernel) against the eight-wave one (gemm_ntp_kernel, the default; VITK_GEMM_NTQ=1 selects the four-wave kernel) on the
 workload's shapes, interleaved rounds in one process: bit equality of the results, then microseconds and TFLOP/s of both.
 usage: python tools/ab_ntq.py [rounds] [reps]"""
 import os

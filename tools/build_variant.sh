@@ -7,7 +7,7 @@ name=$1; src=$2; flags=$3
 csrc=$root/vision_transformers_torch_xla_amd/csrc
 mkdir -p $root/ab /tmp/vitk_ab_$name
 obj=/tmp/vitk_ab_$name/${src%.hip}.o
-extra=""; [ "$src" = gemm.hip ] && extra="-mllvm -amdgpu-atomic-optimizer-strategy=None"      # as build.py's EXTRA_FLAGS
+extra=""; [ "$src" = gemm.hip -o "$src" = gemm_ntq.hip ] && extra="-mllvm -amdgpu-atomic-optimizer-strategy=None"      # as build.py's EXTRA_FLAGS
 [ "$src" = attention.hip ] && extra="-fno-slp-vectorize"
 /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -Wno-unused-function $extra $flags -Wno-inline-asm -Wno-cuda-compat -Wno-pass-failed -c $csrc/$src -o $obj
 others=$(ls $csrc/build/*.o | grep -v "/${src%.hip}.o")

@@ -10,6 +10,14 @@
 // left between two tiles is the transposition of the fp32 accumulators through LDS and the epilogue arithmetic, on fp32 values
 // exactly as in gemm_ntp_kernel: results are bit-identical to that kernel.
 //
+// MEASURED (MI355X, 95 % of 100 864 rows, same process, microseconds eight-wave / this kernel): plain K = 768 99 / 123, K = 2304
+// 281 / 331, K = 3072 387 / 454; bias N = 2304 302 / 383; bias + residual K = 768 145 / 227, K = 3072 422 / 549; multiply N = 3072
+// 442 / 752 - slower everywhere, so the launcher takes it only with VITK_GEMM_NTQ=1.  Per tile round its K-step costs 1.73-2.05 us
+// against 1.51-1.78 and its tile boundary 3.8 us against 1.7: with one wave per SIMD nothing covers the issue time of a wave's 16
+// LDS-DMA instructions per K-step (eight per wave, and the partner wave's MFMAs beside them, in the eight-wave kernel), nor the
+// LDS round trip of the epilogue's transposition; the stores and side loads it moves under the MFMAs were costing the
+// eight-wave kernel less than that.  Kept as the tested record of the experiment (bit-identical results).
+//
 // Vector-memory bookkeeping.  The LDS-DMA requests are inline assembly and counted by hand; the output stores, side loads and
 // bias loads are ordinary (the compiler counts them, but never has to wait for one inside the K loop: their first use is the
 // epilogue).  All of them share the wave's in-order vmcnt counter.  A K-step's wait must cover the request of the NEXT K-step,
@@ -22,6 +30,9 @@
 #define NTQ_STG_FLOATS 2048                                   // per wave: two staging buffers of 16 rows x 64 fp32 (4 KB each)
 #define NTQ_LDS (4 * LTILE * 2 + 4 * NTQ_STG_FLOATS * 4)      // operand image 128 KB + 32 KB of staging = 160 KB
 #define NTQ_MIN_KSTEPS 12                                     // drain (4 steps) + plain + intake (4 steps) + last
+#ifndef NTQ_FRAGS
+#define NTQ_FRAGS 48            // fragment registers of the K loop: 48 (16 phases of 8 MFMAs) or 80 (8 phases of 16 MFMAs)
+#endif
 
 struct NtqRowMap { int bnd, off0, off1; float rs0, rs1; };    // stochastic-depth row mapping of a wave's 128 rows (see gemm_ntp_kernel)
 
@@ -101,7 +112,11 @@ __global__ __launch_bounds__(256) void gemm_ntq_kernel(const GemmNTParams p) {
     // (ks, nh) group stay for its 4 phases while the A fragments come in pairs, one phase ahead, and the next group's B fragments
     // arrive one per phase - 48 fragment registers (a scheme that holds a slice's 8 B fragments and the next slice's needs 80,
     // which the 256 accumulator + 128 held-tile registers do not leave).  Each A fragment is read twice per slice.
+#if NTQ_FRAGS == 80
+    bf16x8 fb0[8], fb1[8], faE[2], faO[2];
+#else
     bf16x8 fbC[4], fbN[4], faE[2], faO[2];
+#endif
     auto ldA2 = [&](bf16x8 (&f)[2], const bf16_t* cA, int ks, int q) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) f[t] = *reinterpret_cast<const bf16x8*>(cA + offA[ks] + (2 * q + t) * 16 * GBK);
@@ -115,6 +130,14 @@ __global__ __launch_bounds__(256) void gemm_ntq_kernel(const GemmNTParams p) {
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
                 acc[2 * q + tm][4 * nh + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], fresh ? zero : acc[2 * q + tm][4 * nh + tn], 0, 0, 0);
+    };
+    auto mma8 = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[8], int q, bool fresh) __attribute__((always_inline)) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 8; ++tn)
+                acc[2 * q + tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], fresh ? zero : acc[2 * q + tm][tn], 0, 0, 0);
     };
     // scheduling of a phase: `mf` MFMAs then one LDS read, `n` times (the rest of the MFMAs follow)
 #define NTQ_SCHED(n, mf)                                                                                                        \
@@ -233,6 +256,40 @@ __global__ __launch_bounds__(256) void gemm_ntq_kernel(const GemmNTParams p) {
         const bf16_t* cB = cA + LTILE;
         const bf16_t* nA = lsm + (par ^ 1) * 2 * LTILE;
         const bf16_t* nB = nA + LTILE;
+#if NTQ_FRAGS == 80
+        // 8 phases of 16 MFMAs: phase (ks, q) multiplies A row tiles 2q, 2q+1 of K-slice ks with the 8 B fragments of the slice; the A
+        // fragments of the next phase and, through slice 0, the B fragments of slice 1 are read while it runs
+        if (pend_k >= 0) stage_q(pend_k, pend_par, itag<1>{});
+        mma8(faE, fb0, 0, FIRST);
+        ldA2(faO, cA, 0, 1); ldB1(fb1[0], cB, 1, 0); ldB1(fb1[1], cB, 1, 1);
+        NTQ_SCHED(4, 4)
+        if (pend_k >= 0) stage_q(pend_k, pend_par, itag<2>{});
+        mma8(faO, fb0, 1, FIRST);
+        ldA2(faE, cA, 0, 2); ldB1(fb1[2], cB, 1, 2); ldB1(fb1[3], cB, 1, 3);
+        NTQ_SCHED(4, 4)
+        if (pend_k >= 0) { stage_q(pend_k, pend_par, itag<3>{}); pend_k = -1; }
+        mma8(faE, fb0, 2, FIRST);
+        ldA2(faO, cA, 0, 3); ldB1(fb1[4], cB, 1, 4); ldB1(fb1[5], cB, 1, 5);
+        NTQ_SCHED(4, 4)
+        // everything ordinary from here to the wait is younger than the request's last quarter: two instructions per phase
+        beside(itag<0>{}); beside(itag<1>{});
+        mma8(faO, fb0, 3, FIRST);
+        ldA2(faE, cA, 1, 0); ldB1(fb1[6], cB, 1, 6); ldB1(fb1[7], cB, 1, 7);
+        NTQ_SCHED(4, 4)
+        beside(itag<2>{}); beside(itag<3>{});
+        mma8(faE, fb1, 0, false);
+        ldA2(faO, cA, 1, 1);
+        NTQ_SCHED(2, 8)
+        beside(itag<4>{}); beside(itag<5>{});
+        mma8(faO, fb1, 1, false);
+        ldA2(faE, cA, 1, 2);
+        NTQ_SCHED(2, 8)
+        beside(itag<6>{}); beside(itag<7>{});
+        if (BLD) { load_bias(); __builtin_amdgcn_sched_barrier(0); }
+        mma8(faE, fb1, 2, false);
+        ldA2(faO, cA, 1, 3);
+        NTQ_SCHED(2, 8)
+#else
         // phase (g, q), g = 2 ks + nh: 8 MFMAs of row pair q with the group's B fragments (fbC for even g, fbN for odd g); beside
         // them the reads of the next phase's A pair and of one B fragment of the next group
 #define NTQ_PHASE(G_, Q_, FA_CUR, FA_NXT, FB_CUR, FB_NXT)                                                                      \
@@ -273,6 +330,7 @@ __global__ __launch_bounds__(256) void gemm_ntq_kernel(const GemmNTParams p) {
         if (BLD) { load_bias(); __builtin_amdgcn_sched_barrier(0); }
         NTQ_PHASE(3, 2, faE, faO, fbN, fbC)
 #undef NTQ_PHASE
+#endif
         // every wave has issued its last read of the current buffer; the next K-step, requested a full step ago, must have landed:
         // publish it, then refill the current buffer with the K-step after that
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EXTRA) : "memory");
@@ -300,11 +358,19 @@ __global__ __launch_bounds__(256) void gemm_ntq_kernel(const GemmNTParams p) {
             if (pend_k >= 0) stage_q(pend_k, pend_par, itag<0>{});
         }
         // last phase: the first fragments of the next K-step out of the other buffer (after the last tile: stale LDS, never used)
+#if NTQ_FRAGS == 80
+        mma8(faO, fb1, 3, false);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ldB1(fb0[t], nB, 0, t);
+        ldA2(faE, nA, 0, 0);
+        NTQ_SCHED(10, 1)
+#else
         mma(faO, fbN, 3, 1, false);
 #pragma unroll
         for (int t = 0; t < 4; ++t) ldB1(fbC[t], nB, 0, t);
         ldA2(faE, nA, 0, 0);
         NTQ_SCHED(6, 1)
+#endif
         par ^= 1;
     };
 
@@ -376,8 +442,13 @@ __global__ __launch_bounds__(256) void gemm_ntq_kernel(const GemmNTParams p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     stage_q(1, 1, itag<0>{}); stage_q(1, 1, itag<1>{}); stage_q(1, 1, itag<2>{}); stage_q(1, 1, itag<3>{});
+#if NTQ_FRAGS == 80
+#pragma unroll
+    for (int t = 0; t < 8; ++t) ldB1(fb0[t], lsm + LTILE, 0, t);
+#else
 #pragma unroll
     for (int t = 0; t < 4; ++t) ldB1(fbC[t], lsm + LTILE, 0, t);
+#endif
     ldA2(faE, lsm, 0, 0);
 
     for (;;) {
@@ -436,8 +507,10 @@ __global__ __launch_bounds__(256) void gemm_ntq_kernel(const GemmNTParams p) {
 // the problems this kernel takes (the others stay with gemm_ntp_kernel): the four epilogues with at most one bf16 output, K long
 // enough for the drain / intake schedule, and - bias + residual under stochastic depth - samples of 128 rows or more
 bool vitk_gemm_ntq_takes(const GemmNTParams& p, int epilogue) {
-    const char* env = getenv("VITK_GEMM_NTQ");       // read at every call: tests run both kernels in one process
-    if (env != nullptr && env[0] == '0') return false;
+    // Off unless VITK_GEMM_NTQ=1: measured on MI355X this kernel is 8-40 % slower than gemm_ntp_kernel on the ViT shapes (see the
+    // header).  The variable is read at every call: the parity test runs both kernels in one process.
+    const char* env = getenv("VITK_GEMM_NTQ");
+    if (env == nullptr || env[0] != '1') return false;
     if (epilogue != VITK_EPI_PLAIN && epilogue != VITK_EPI_BIAS && epilogue != VITK_EPI_BIAS_RES && epilogue != VITK_EPI_MUL) return false;
     if (p.K / GBK < NTQ_MIN_KSTEPS) return false;
     if (epilogue == VITK_EPI_BIAS_RES && (p.smap != nullptr || p.rowscale != nullptr)) {
