@@ -220,6 +220,15 @@ int vitk_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream
 int vitk_preprocess_images(const void* src, int src_is_u8, const unsigned char* flip, float* dst, int B, int H, int W,
                            int src_h, int src_w, int top, int left, float vmin, float vmax, const float* mean3,
                            const float* std3, void* stream);
+/* The same chain writing what the model's first GEMM reads instead of the fp32 NCHW batch: dst = the bf16 patch matrix
+ * [B * (H/patch) * (W/patch), 3 * patch * patch], row = image b, patch gy * (W/patch) + gx, column = c * patch^2 + ky * patch + kx
+ * (the operand order of Conv2d(3, D, k = s = patch) + flatten(2).transpose(1, 2), models/vision_transformer.py:552-560,936), each
+ * value rounded to bf16 once.  Bit-identical to vitk_im2col_patches(vitk_preprocess_images(src)): the NHWC window goes straight to
+ * the patch matrix, without the fp32 NCHW batch written and read in between (datasets.py:301-314 hands the reference's model CHW
+ * float32).  patch % 8 == 0, H % patch == W % patch == 0. */
+int vitk_preprocess_patches(const void* src, int src_is_u8, const unsigned char* flip, void* dst, int patch, int B, int H, int W,
+                            int src_h, int src_w, int top, int left, float vmin, float vmax, const float* mean3,
+                            const float* std3, void* stream);
 
 /* ---- crop / resize stage of the input pipeline on the device: B decoded images of DIFFERENT sizes (uint8 HWC, 3 channels, packed
  * one after the other in src; already on the device) become the fp32 NCHW batch dst [B, 3, S, S].  Per image a descriptor says
@@ -245,6 +254,13 @@ typedef struct {
 int vitk_resample_images(const unsigned char* src, int64_t src_bytes, const vitk_resample_desc* desc_host,
                          const vitk_resample_desc* desc_dev, float* dst, int B, int S, int kernel, float vmin, float vmax,
                          const float* mean3, const float* std3, void* stream);
+/* the same writing the model's bf16 patch matrix [B * (S/patch)^2, 3 * patch^2] (layout: vitk_preprocess_patches) instead of the
+ * fp32 NCHW batch: bit-identical to vitk_im2col_patches(vitk_resample_images(...)).  Both entry points validate desc_host and
+ * read desc_dev on the device; the kernel clamps every source offset it derives from desc_dev to the source buffer, so a device
+ * copy that does not match the host one gives wrong pixels, never an access outside src. */
+int vitk_resample_patches(const unsigned char* src, int64_t src_bytes, const vitk_resample_desc* desc_host,
+                          const vitk_resample_desc* desc_dev, void* patches, int patch, int B, int S, int kernel, float vmin,
+                          float vmax, const float* mean3, const float* std3, void* stream);
 
 /* ---- mixup / cutmix in 'batch' mode on the device, in place on the fp32 NCHW batch x [B, per_sample]; sample b is paired
  * with sample B-1-b (x.flip(0)); B must be even.  Replaces timm.data.Mixup.__call__ as the reference applies it before

@@ -159,8 +159,8 @@ def generate_random_crop(width: int, height: int, min_area_frac: float, max_area
         area = float(w * h)
     if area < min_area or area > max_area or w > width or h > height or w <= 0 or h <= 0:
         return False, None
-    y = uniform(height - h + 1) if h < height else 0
-    x = uniform(width - w + 1) if w < width else 0
+    y = uniform(height - h) if h < height else 0        # the op draws random->Uniform(original - size): the origin is in [0, H - h)
+    x = uniform(width - w) if w < width else 0
     return True, (x, y, x + w, y + h)
 
 

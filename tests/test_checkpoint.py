@@ -72,3 +72,17 @@ def test_finetune_drops_head_and_resamples_pos_embed(tmp_path):
     # identity when the grid does not change
     assert utils.resample_abs_pos_embed(src.pos_embed.detach(), (14, 14)) is not None
     assert torch.equal(utils.resample_abs_pos_embed(src.pos_embed.detach(), (14, 14)), src.pos_embed.detach())
+
+
+def test_finetune_from_1000_classes_onto_37(tmp_path):
+    """main.py:653-674: --finetune loads a checkpoint trained on 1000 classes into a model with another head; the mismatched head is
+    dropped, everything else is taken.  37 is not a multiple of 8 (the head then runs on zero-padded copies on the GPU)."""
+    torch.manual_seed(0)
+    src = create_model("vit_tiny_patch16_224", num_classes=1000, global_pool="avg", depth=1)
+    torch.save({"model": src.state_dict()}, tmp_path / "in1k.pth")
+    dst = create_model("vit_tiny_patch16_224", num_classes=37, global_pool="avg", depth=1)
+    assert dst.head.weight.shape == (37, 192) and dst._pad_head and dst._cls_pad == 40
+    missing, unexpected = utils.load_finetune_checkpoint(dst, tmp_path / "in1k.pth")
+    assert sorted(missing) == ["head.bias", "head.weight"] and unexpected == []
+    assert torch.equal(dst.blocks[0].mlp.fc1.weight, src.blocks[0].mlp.fc1.weight)
+    assert set(dst.state_dict()) == set(src.state_dict()) and dst.state_dict()["head.weight"].shape == (37, 192)

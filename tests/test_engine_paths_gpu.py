@@ -162,6 +162,39 @@ def test_graphed_step_is_the_eager_step(device, monkeypatch, kd):
     assert torch.equal(p_g, p_e)
 
 
+def test_graphed_step_survives_epochs_and_fills_param_grads(device, monkeypatch):
+    """The captured step is kept from one train_one_epoch call to the next (one capture, not one per epoch), and after a replay -
+    which runs no Python - every parameter's .grad is the view of the flat gradient buffer the replayed kernels wrote: torch's own
+    clip_grad_norm_ (a reader of p.grad) sees the same norm as the library's clipping."""
+    from vision_transformers_torch_xla_amd import engine, optim_factory, utils
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+    monkeypatch.setenv("VITK_GRAPH_STEP", "1")
+    data = [_batch(8, 224, 40, 800 + i) for i in range(5)]
+    torch.manual_seed(5)
+    m = create_model("vit_tiny_patch16_224", num_classes=40, global_pool="avg", drop_path_rate=0.1, depth=2).to(device)
+    crit = LabelSmoothingCrossEntropy(0.1)
+    opt = optim_factory.create_optimizer(_Args, m)
+    before = engine.GraphedStep.total_replays
+    engine.train_one_epoch(m, crit, data, opt, device, 0, None, 0, None, None, update_freq=1, log_freq=1)
+    assert engine.GraphedStep.total_replays - before == 3          # two eager steps, then the capture and replays
+    held = m._vitk_graphed_step
+    assert held.graph is not None and m._static_drop is None
+    engine.train_one_epoch(m, crit, data, opt, device, 1, None, 0, None, None, update_freq=1, log_freq=1)
+    assert m._vitk_graphed_step is held and engine.GraphedStep.total_replays - before == 8     # the second epoch replays all five steps
+    # one more replayed step by hand: gradients through p.grad
+    held.resume()
+    x, y = data[0]
+    opt.zero_grad()
+    assert all(p.grad is None for p in m.parameters())
+    held.step(x.to(device), y.to(device))
+    held.pause()
+    assert m._grad_valid and all(p.grad is not None and p.grad.data_ptr() == m._gview[n].data_ptr() for n, p in m.named_parameters())
+    flat_norm = m._flat["g"].double().norm().item()
+    torch_norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 1e9).item()
+    assert abs(torch_norm - flat_norm) <= 1e-5 * flat_norm and flat_norm > 0
+
+
 def test_kd_loss_gradient_matches_autograd(device):
     """the fused criterion on identical logits: value and d/d(student logits) against autograd through the oracle's formula"""
     from oracle import ref_ops as R

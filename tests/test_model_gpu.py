@@ -334,6 +334,56 @@ def test_padded_heads_match_the_unpadded_kernels(device, name, hd, hp):
     assert rel_l2(out_p, out_g) <= E2E_TOL and rel_l2(g_p, m._flat["g"]) <= E2E_GRAD_TOL
 
 
+@pytest.mark.parametrize("classes,pool,name", [(37, "avg", "vit_tiny_patch16_224"), (100, "token", "vit_tiny_patch16_224"),
+                                               (1, "avg", "vit_tiny_patch16_224"), (37, "token", "deit_tiny_distilled_patch16_224")])
+def test_class_counts_that_are_not_multiples_of_8(device, classes, pool, name):
+    """--nb_classes is free in the reference (main.py:643-649; fine-tuning onto 37 or 100 classes is its stated use, :653-674).
+    The head GEMMs run on zero-padded bf16 copies: logits, loss and every gradient against the oracle, the parameters keep
+    timm's shapes, a second backward accumulates, and one optimizer step leaves finite weights."""
+    from vision_transformers_torch_xla_amd import optim_factory
+    ref, m = _pair(name, device, depth=2, num_classes=classes, global_pool=pool, dpr=0.1)
+    distilled = "distilled" in name
+    if distilled:
+        ref.set_distilled_training(True); m.set_distilled_training(True)
+    assert tuple(m.head.weight.shape) == (classes, m.embed_dim) and tuple(m.head.bias.shape) == (classes,)
+    assert m._pad_head == (classes % 8 != 0)
+    B = 4
+    x, y = _batch(B, 224, classes, 29)
+    ref.train()
+    scales = ref.make_drop_scales(B, generator=torch.Generator().manual_seed(8))
+    out, loss_ref, got, loss = _train_step_grads(ref, m, device, x, y, scales, distilled=distilled, emulate=True)
+    outs = got if isinstance(got, tuple) else (got,)
+    wants = out if isinstance(out, tuple) else (out,)
+    for g_, w_ in zip(outs, wants):
+        assert tuple(g_.shape) == (B, classes) and g_.is_contiguous()
+        assert rel_l2(g_, w_) <= E2E_TOL
+    assert abs(loss.item() - loss_ref.item()) <= E2E_TOL * abs(loss_ref.item())
+    refp = dict(ref.named_parameters())
+    for n in ["head.weight", "head.bias"] + (["head_dist.weight", "head_dist.bias"] if distilled else []):
+        assert rel_l2(m._gview[n], refp[n].grad) <= E2E_GRAD_TOL, n
+    gv, rv = _gradvec(m, ref)
+    assert rel_l2(gv, rv) <= E2E_GRAD_TOL
+    if classes > 1:
+        from vision_transformers_torch_xla_amd import ops
+        assert torch.equal(ops.argmax_rows(outs[0].detach()).cpu(), outs[0].detach().cpu().max(-1)[-1])
+    g1 = m._flat["g"].clone()
+    m._forced_drop_scales = scales
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    crit, crit0 = LabelSmoothingCrossEntropy(0.1), LabelSmoothingCrossEntropy(0.0)
+    o2 = m(x.to(device))
+    (crit(o2[0], y.to(device)) + 0.5 * crit0(o2[1], y.to(device)) if distilled else crit(o2, y.to(device))).backward()
+    assert rel_l2(m._flat["g"], 2 * g1) <= 1e-6                      # accumulates through the padded head products too
+
+    class A:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 1e-3, 0.05, 1e-8, None
+    optim_factory.create_optimizer(A, m).step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    with torch.no_grad():
+        m.eval()
+        assert tuple(m(x.to(device)).shape) == (B, classes)           # the padded copies follow the optimizer step
+
+
 def test_grad_accumulation_and_zero_grad(device):
     ref, m = _pair("vit_tiny_patch16_224", device, depth=2)
     x, y = _batch(4, 224, 40, 11)

@@ -85,6 +85,77 @@ def test_kernel_bit_exact(kind, B, H, W, window):
     assert torch.equal(nofl.cpu(), RP.preprocess_batch(imgs, None, normalize="none", window=window))
 
 
+def _patch_matrix(nchw, p):
+    """the model's patch matrix of an fp32 NCHW batch: row = patch (b, gy, gx), column = c * p^2 + ky * p + kx, rounded to bf16
+    once (round to nearest even) - the operand order of the patch-embedding GEMM (vision_transformer.py PatchEmbed: Conv2d with
+    kernel = stride = patch, weight [D, C, p, p] flattened)"""
+    B, C, H, W = nchw.shape
+    return nchw.reshape(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B * (H // p) * (W // p), C * p * p).to(torch.bfloat16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["u8", "f32"])
+@pytest.mark.parametrize("B,H,W,window,p", [(5, 224, 224, None, 16), (3, 32, 24, None, 8), (2, 256, 341, (16, 58, 224, 224), 16),
+                                            (2, 40, 37, (3, 5, 32, 32), 16), (1, 384, 384, None, 32), (2, 224, 224, None, 14)])
+def test_patch_matrix_output_bit_exact(kind, B, H, W, window, p):
+    """patch=p: the bf16 patch matrix straight from the NHWC batch == im2col of the fp32 batch the two-kernel route writes"""
+    from vision_transformers_torch_xla_amd import _lib, data, ops
+    imgs = _images(kind, B, H, W, seed=B * 77 + W)
+    flips = np.random.default_rng(11).integers(0, 2, size=B).astype(np.uint8)
+    flips[0] = 1
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(imgs).to(dev)
+    fl = torch.from_numpy(flips).to(dev)
+    if p % 8:
+        with pytest.raises(_lib.VitkError, match="multiple of 8"):
+            ops.preprocess_images(src, flip=fl, window=window, patch=p)
+        return
+    for vr, norm in (((0.0, 1.0), "imagenet"), ((-1.0, 1.0), "none")):
+        mean, std = (data.IMAGENET_DEFAULT_MEAN, data.IMAGENET_DEFAULT_STD) if norm == "imagenet" else (None, None)
+        got = ops.preprocess_images(src, flip=fl, window=window, value_range=vr, mean=mean, std=std, patch=p)
+        want = _patch_matrix(RP.preprocess_batch(imgs, flips, vmin=vr[0], vmax=vr[1], normalize=norm, window=window), p)
+        assert got.dtype == torch.bfloat16 and got.shape == want.shape
+        assert torch.equal(got.cpu(), want), (kind, vr, norm)
+        two = ops.im2col_patches(ops.preprocess_images(src, flip=fl, window=window, value_range=vr, mean=mean, std=std), p)
+        assert torch.equal(got, two)
+    nofl = ops.preprocess_images(src, window=window, patch=p)
+    assert torch.equal(nofl.cpu(), _patch_matrix(RP.preprocess_batch(imgs, None, normalize="none", window=window), p))
+
+
+@pytest.mark.gpu
+def test_model_takes_the_patch_matrix():
+    """VisionTransformer.forward on the loader's patch matrix == forward on the fp32 batch (logits and every gradient, bit for
+    bit), through train_one_epoch and evaluate as well (the batch size there comes from the labels)"""
+    from vision_transformers_torch_xla_amd import data, engine, optim_factory, vit
+    from vision_transformers_torch_xla_amd.losses import CrossEntropyLoss
+
+    class A:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 1e-3, 0.05, 1e-8, None
+    dev = torch.device("cuda:0")
+    B, n = 8, 3
+    host = [(_images("u8", B, 64, 64, seed=40 + i), (np.arange(B) * 3 + i) % 16) for i in range(n)]
+
+    def run(patch):
+        torch.manual_seed(5)
+        m = vit.VisionTransformer(img_size=64, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_classes=16).to(dev)
+        opt = optim_factory.create_optimizer(A, m)
+        loader = data.DeviceLoader(host, dev, flip_lr=True, seed=1, patch=patch)
+        first = next(iter(loader))[0]
+        stats = engine.train_one_epoch(m, CrossEntropyLoss(), loader, opt, dev, epoch=0)
+        ev = engine.evaluate(data.DeviceLoader(host, dev, patch=patch), m, dev)
+        return first, stats, ev, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    img, s_img, e_img, w_img = run(None)
+    pat, s_pat, e_pat, w_pat = run(16)
+    assert pat.dtype == torch.bfloat16 and pat.shape == (B * 16, 3 * 256) and img.shape == (B, 3, 64, 64)
+    assert s_img == s_pat and e_img == e_pat
+    for k in w_img:
+        assert torch.equal(w_img[k], w_pat[k]), k
+    m = vit.VisionTransformer(img_size=64, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_classes=16).to(dev)
+    with pytest.raises(Exception, match="patch matrix"):
+        m(pat[:, :100].contiguous())
+
+
 @pytest.mark.gpu
 def test_every_u8_value_and_flip_is_an_involution():
     from vision_transformers_torch_xla_amd import data, ops
@@ -106,7 +177,7 @@ def test_device_loader_matches_host_pipeline():
     host = [(_images("u8", B, 256, 288, seed=i), np.arange(B) + 10 * i) for i in range(n)]
     loader = data.DeviceLoader(host, "cuda:0", flip_lr=True, crop=224, seed=3)
     assert len(loader) == n
-    for epoch in (1, 2):
+    for epoch in (0, 1):                                     # no set_epoch: the loader counts its own iterations from 0
         gen = torch.Generator().manual_seed(3 + epoch)
         seen = 0
         for (samples, targets), (imgs, labels) in zip(loader, host):

@@ -77,6 +77,36 @@ def test_host_geometry_matches_oracle():
     assert (small[0]["win_y"], small[0]["win_x"]) == (-18, 2)
 
 
+def test_crop_origin_range_epoch_seeding_and_oversize_images():
+    from vision_transformers_torch_xla_amd import data
+    # origin uniform over [0, H - h): with a 2-row image and 1-row boxes the origin H - h itself is never drawn ...
+    rng = np.random.default_rng(3)
+    tops = set()
+    for _ in range(400):
+        y, x, bh, bw = data.sample_inception_box(40, 40, rng, area=(0.9, 0.95), ratio=(1.0, 1.0))
+        if (bh, bw) != (40, 40):
+            assert y + bh < 40 and x + bw < 40, (y, x, bh, bw)
+            tops.add(y)
+    assert tops and 0 in tops
+    # images the kernel cannot take whole are halved (2 x 2 means) until they fit; others come back untouched
+    im = _img(8, 8, 0)
+    assert data.fit_for_resample(im, 224) is im
+    wide = np.zeros((4, 2 * data.MAX_SOURCE_WIDTH, 3), np.uint8)
+    wide[0::2, 0::2] = 3; wide[1::2, 0::2] = 4; wide[0::2, 1::2] = 5; wide[1::2, 1::2] = 7
+    out = data.fit_for_resample(wide, 224)
+    assert out.shape == (2, data.MAX_SOURCE_WIDTH, 3) and out.dtype == np.uint8 and (out == 5).all()      # (3+4+5+7+2) >> 2
+    tall = np.full((data.MAX_ROW_REDUCTION * 8 + 9, 6, 3), 200, np.uint8)
+    assert data.fit_for_resample(tall, 8).shape[0] <= data.MAX_ROW_REDUCTION * 8
+
+    class Host(list):
+        def set_epoch(self, e):
+            self.epoch = e
+    # set_epoch(e) -> the draws of Generator(seed + e), the same ones every time epoch e is iterated
+    ld = data.ResampleLoader(Host(), "cpu", seed=7)
+    ld.set_epoch(4)
+    assert ld.batches.epoch == 4 and ld._epoch == 4
+
+
 def test_resample_entry_point_validates_on_the_host():
     """bad descriptors are refused before anything is launched (no GPU needed to see that)"""
     from vision_transformers_torch_xla_amd import _lib, ops
@@ -136,6 +166,40 @@ def test_resample_kernel_is_bit_exact_with_the_oracle(device, kernel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["triangle", "keyscubic"])
+def test_resample_to_the_patch_matrix_is_bit_exact(device, kernel):
+    """patch=p: crop + resize + flip + normalise written as the model's bf16 patch matrix == im2col of the fp32 result (oracle
+    and two-kernel route), padded rows and flipped images included; the loader's patch option hands the same matrix on"""
+    from vision_transformers_torch_xla_amd import _lib, data, ops
+    from vision_transformers_torch_xla_amd.data import IMAGENET_DEFAULT_MEAN as M, IMAGENET_DEFAULT_STD as SD
+    images = [_img(h, w, 30 + i) for i, (h, w) in enumerate([(120, 160), (64, 48), (333, 500), (40, 40), (90, 17)])]
+    flat, offs = data.pack_images(images)
+    size, p = 64, 16
+    boxes = [(10, 20, 100, 120), (0, 0, 64, 48), (33, 100, 280, 390), (5, 5, 30, 30), (0, 0, 90, 17)]
+    train = data.train_descriptors(images, offs, size, None, boxes=boxes, flips=[0, 1, 1, 0, 1])
+    evald = data.eval_descriptors(images, offs, 72, size)
+    evald[4]["flip"] = 1
+    src = torch.from_numpy(flat).to(device)
+
+    def matrix(nchw):
+        B, C, H, W = nchw.shape
+        return nchw.reshape(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B * (H // p) * (W // p), C * p * p).to(torch.bfloat16)
+    for desc in (train, evald):
+        got = ops.resample_images(src, desc, size, kernel=kernel, mean=M, std=SD, patch=p)
+        assert got.dtype == torch.bfloat16 and got.shape == (len(images) * 16, 3 * p * p)
+        assert torch.equal(got.cpu(), matrix(_oracle_batch(images, desc, size, kernel)))
+        assert torch.equal(got, ops.im2col_patches(ops.resample_images(src, desc, size, kernel=kernel, mean=M, std=SD), p))
+    with pytest.raises(_lib.VitkError, match="multiple of 8"):
+        ops.resample_images(src, train, size, kernel=kernel, patch=12)
+    with pytest.raises(_lib.VitkError, match="divides"):
+        ops.resample_images(src, train, 56, kernel=kernel, patch=16)
+    host = [(images, np.arange(len(images)))]
+    (x, y), = list(data.ResampleLoader(host, device, size=size, train=False, resize=72, patch=p))
+    evald[4]["flip"] = 0
+    assert torch.equal(x.cpu(), matrix(_oracle_batch(images, evald, size, "keyscubic"))) and y.tolist() == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.gpu
 def test_resample_loader_over_an_image_folder(device, tmp_path):
     """decode (PIL) -> pack -> GPU crop / resize / flip / normalise, for the training and the evaluation chain, against the oracle
     composed from the same decoded pixels and the loader's own draws"""
@@ -154,7 +218,7 @@ def test_resample_loader_over_an_image_folder(device, tmp_path):
         seen = 0
         ref_folder = data.DecodedImageFolder(str(tmp_path), batch_size=3, shuffle=True, seed=5, workers=1)
         ref_folder.set_epoch(2)
-        rng = np.random.default_rng(11 + 3)                             # the loader's epoch counter after set_epoch(2) + iteration start
+        rng = np.random.default_rng(11 + 2)                             # epoch 2's draws: Generator(seed + epoch)
         for (x, y), (imgs, labels) in zip(loader, ref_folder):
             flat, offs = data.pack_images(imgs)
             desc = data.train_descriptors(imgs, offs, 32, rng) if train else data.eval_descriptors(imgs, offs, 40, 32)

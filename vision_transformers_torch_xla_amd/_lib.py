@@ -69,7 +69,9 @@ SIGNATURES = {
     "vitk_add_bf16": (_i, [_p, _p, _p, _i64, _p]),
     "vitk_copy_from_host": (_i, [_p, _p, _i64, _p]),
     "vitk_preprocess_images": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p, _p]),
+    "vitk_preprocess_patches": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p, _p]),
     "vitk_resample_images": (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _f, _f, _p, _p, _p]),
+    "vitk_resample_patches": (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _p, _p]),
     "vitk_mixup_batch": (_i, [_p, _i, _i64, _f, _f, _p]),
     "vitk_cutmix_batch": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vitk_mixup_targets": (_i, [_p, _p, _i, _i, _i, _f, _f, _f, _f, _p]),

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_ntq_kernel(const GemmNTParams p) {
             for (int tn = 0; tn < 4; ++tn)
                 acc[2 * q + tm][4 * nh + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], fresh ? zero : acc[2 * q + tm][4 * nh + tn], 0, 0, 0);
     };
-    auto mma8 = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[8], int q, bool fresh) __attribute__((always_inline)) {
+    [[maybe_unused]] auto mma8 = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[8], int q, bool fresh) __attribute__((always_inline)) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)

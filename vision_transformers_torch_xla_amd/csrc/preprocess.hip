@@ -132,19 +132,37 @@ static __device__ __forceinline__ float resample_weight(const ResampleAxis& a, i
     return resample_kernel(kind, pos * a.one_over);
 }
 
-#define RESAMPLE_MAX_TAPS 512      // vertical taps kept in LDS: covers a 60-fold reduction with the cubic kernel
+#define RESAMPLE_MAX_TAPS 512      // vertical taps kept in LDS: covers a 127-fold reduction with the cubic kernel (2 * 2 * 127 + 3 taps)
 
+// dst: fp32 NCHW [B, 3, S, S] - or, with patches != null, the model's bf16 patch matrix [B * (S/patch)^2, 3 * patch^2] (row =
+// patch gy * (S/patch) + gx of image b, column c * patch^2 + ky * patch + kx: the operand order of the patch-embedding GEMM),
+// each value rounded to bf16 once, as the im2col kernel rounds the fp32 image.
+// The descriptors the kernel reads are the caller's DEVICE copy; the host copy was validated.  So that a stale or mismatched
+// device copy cannot turn into an access outside the buffers, every source byte offset is clamped to the source buffer and the
+// box width to the width the LDS row was sized for.
 __global__ __launch_bounds__(256) void resample_kernel_rows(const unsigned char* __restrict__ src, const vitk_resample_desc* __restrict__ desc,
                                                             float* __restrict__ dst, int S, int kind, float scale, float vmin, int normalise,
-                                                            float m0, float m1, float m2, float s0, float s1, float s2) {
+                                                            float m0, float m1, float m2, float s0, float s1, float s2,
+                                                            bf16_t* __restrict__ patches, int patch, long long src_bytes, int max_box_w) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float rs_smem[];
     float* wy = rs_smem;                               // [RESAMPLE_MAX_TAPS] normalised vertical weights of this output row
     float* inter = rs_smem + RESAMPLE_MAX_TAPS;        // [box_w][3] vertically filtered row
     const int b = blockIdx.x / S, y = blockIdx.x % S;
-    const vitk_resample_desc d = desc[b];
+    vitk_resample_desc d = desc[b];
+    d.box_w = min(max(d.box_w, 1), max_box_w);
+    d.box_h = max(d.box_h, 1);
+    d.out_w = max(d.out_w, 1);
+    d.out_h = max(d.out_h, 1);
     const size_t plane = (size_t)S * S;
-    float* out_row = dst + (size_t)b * 3 * plane + (size_t)y * S;
+    float* out_row = patches ? nullptr : dst + (size_t)b * 3 * plane + (size_t)y * S;
+    // patch-matrix output: this output row is row y % patch of the patches gy = y / patch
+    const int gw = patches ? S / patch : 1;
+    bf16_t* prow = patches ? patches + ((size_t)b * gw * gw + (size_t)(y / patch) * gw) * 3 * patch * patch + (size_t)(y % patch) * patch : nullptr;
+    auto put = [&](int x, int c, float v) {
+        if (patches) prow[(size_t)(x / patch) * 3 * patch * patch + (size_t)c * patch * patch + (x % patch)] = f2bf(v);
+        else out_row[c * plane + x] = v;
+    };
     const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
     auto finish = [&](float t, int c) {                // value_range (float input) and normalisation, as vitk_preprocess_images
         t = t * scale + vmin;
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(256) void resample_kernel_rows(const unsigned char*
     if (oy < 0 || oy >= d.out_h) {                      // a padded row (the resized image is shorter than the window)
         for (int x = threadIdx.x; x < S; x += blockDim.x)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) out_row[c * plane + x] = finish(0.0f, c);
+            for (int c = 0; c < 3; ++c) put(x, c, finish(0.0f, c));
         return;
     }
     const ResampleAxis ay = resample_axis(d.box_h, d.out_h, kind);
@@ -170,15 +188,16 @@ __global__ __launch_bounds__(256) void resample_kernel_rows(const unsigned char*
     const bool ynorm = fabsf(ytotal) >= 1000.0f * 1.17549435e-38f;
     const float yinv = 1.0f / ytotal;
     // vertical pass: inter[col][c] = sum_i (wy[i] * yinv) * (u8 * (1/255))
-    const unsigned char* box = src + d.src_offset + ((size_t)(d.box_y + ys) * d.src_w + d.box_x) * 3;
-    const size_t row_bytes = (size_t)d.src_w * 3;
+    const long long box = (long long)d.src_offset + ((long long)(d.box_y + ys) * d.src_w + d.box_x) * 3;
+    const long long row_bytes = (long long)d.src_w * 3;
     const float k255 = (float)(1.0 / 255.0);
     for (int e = threadIdx.x; e < d.box_w * 3; e += blockDim.x) {
         float acc = 0.0f;
-        const unsigned char* p = box + e;
         for (int i = 0; i < yn; ++i) {
             const float w = ynorm ? wy[i] * yinv : 0.0f;
-            const float v = (float)p[(size_t)i * row_bytes] * k255;
+            long long at = box + e + (long long)i * row_bytes;
+            at = at < 0 ? 0 : (at < src_bytes ? at : src_bytes - 1);
+            const float v = (float)src[at] * k255;
             acc = acc + w * v;
         }
         inter[e] = acc;
@@ -199,33 +218,130 @@ __global__ __launch_bounds__(256) void resample_kernel_rows(const unsigned char*
             const float inv = 1.0f / total;
             for (int i = 0; i < xn; ++i) {
                 const float w = norm ? resample_weight(ax, kind, xs + i, xsample) * inv : 0.0f;
-                const float* q = inter + (size_t)(xs + i) * 3;
+                const float* q = inter + (size_t)min(xs + i, d.box_w - 1) * 3;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) r[c] = r[c] + w * q[c];
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) out_row[c * plane + x] = finish(r[c], c);
+        for (int c = 0; c < 3; ++c) put(x, c, finish(r[c], c));
     }
 }
+
+// NHWC window -> bf16 patch matrix, the device tail of the input pipeline for a consumer that is the model itself: one item = 8
+// consecutive pixels of one patch row (24 contiguous source elements, reversed when the sample is flipped) -> three 16-byte
+// stores, one per channel, at column c * p^2 + ky * p + kx0 of the patch's row; consecutive items are consecutive 16-byte chunks
+// of a patch's channel plane (p^2 * 2 contiguous bytes), so a wave's stores cover whole lines.  Same arithmetic and LDS table as
+// images_to_nchw_kernel, then one rounding to bf16 - what vitk_im2col_patches makes of that kernel's fp32 output, bit for bit.
+template <bool U8>
+__global__ __launch_bounds__(256) void images_to_patches_kernel(const void* __restrict__ src_, const unsigned char* __restrict__ flip,
+                                                                 bf16_t* __restrict__ dst, int B, int H, int W, int Hs, int Ws, int top,
+                                                                 int left, int p, float scale, float vmin, int normalise, float m0, float m1,
+                                                                 float m2, float s0, float s1, float s2) {
+#pragma clang fp contract(off)
+    __shared__ float tab[U8 ? 3 * 256 : 1];
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    if (U8) {
+        for (int k = threadIdx.x; k < 3 * 256; k += blockDim.x) {
+            const int c = k >> 8;
+            float t = (float)(k & 255) / 255.0f;
+            t = t * scale + vmin;
+            if (normalise) t = (t - mean[c]) / stdv[c];
+            tab[k] = t;
+        }
+        __syncthreads();
+    }
+    const int gw = W / p, gh = H / p, kg = p / 8;
+    const size_t per_patch = (size_t)p * kg;
+    const size_t total = (size_t)B * gh * gw * per_patch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t patch_id = i / per_patch;
+        const int in_patch = (int)(i - patch_id * per_patch);
+        const int ky = in_patch / kg, kx0 = (in_patch - ky * kg) * 8;
+        const int gx = (int)(patch_id % gw);
+        const size_t t2 = patch_id / gw;
+        const int gy = (int)(t2 % gh), b = (int)(t2 / gh);
+        const bool fl = flip != nullptr && flip[b] != 0;
+        const int y = gy * p + ky, x = gx * p + kx0;
+        const int sx = fl ? W - 8 - x : x;                              // first source pixel of the group
+        const size_t e0 = (((size_t)b * Hs + top + y) * Ws + left + sx) * 3;
+        float v[24];
+        if (U8) {
+            const unsigned char* s = static_cast<const unsigned char*>(src_) + e0;
+            unsigned u[24];
+            if ((reinterpret_cast<uintptr_t>(s) & 7) == 0) {
+                const uint2 w0 = *reinterpret_cast<const uint2*>(s), w1 = *reinterpret_cast<const uint2*>(s + 8), w2 = *reinterpret_cast<const uint2*>(s + 16);
+                const unsigned ww[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+#pragma unroll
+                for (int k = 0; k < 24; ++k) u[k] = (ww[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 24; ++k) u[k] = s[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 24; ++k) v[k] = tab[(k % 3) * 256 + u[k]];
+        } else {
+            const float* s = static_cast<const float*>(src_) + e0;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) v[k] = s[k];
+        }
+        bf16_t* o = dst + patch_id * 3 * p * p + (size_t)ky * p + kx0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float q[8];
+#pragma unroll
+            for (int px = 0; px < 8; ++px) {
+                float t = v[(fl ? 7 - px : px) * 3 + c];
+                if (!U8) {
+                    t = t * scale + vmin;
+                    if (normalise) t = (t - mean[c]) / stdv[c];
+                }
+                q[px] = t;
+            }
+            store8(o + (size_t)c * p * p, q);
+        }
+    }
+}
+
+static int resample_impl(const unsigned char* src, int64_t src_bytes, const vitk_resample_desc* desc_host,
+                         const vitk_resample_desc* desc_dev, float* dst, bf16_t* patches, int patch, int B, int S, int kernel, float vmin,
+                         float vmax, const float* mean3, const float* std3, void* stream);
 
 extern "C" {
 
 int vitk_resample_images(const unsigned char* src, int64_t src_bytes, const vitk_resample_desc* desc_host,
                          const vitk_resample_desc* desc_dev, float* dst, int B, int S, int kernel, float vmin, float vmax,
                          const float* mean3, const float* std3, void* stream) {
-    VITK_REQUIRE(src && desc_host && desc_dev && dst && B > 0 && src_bytes > 0, "resample_images: bad arguments");
+    VITK_REQUIRE(dst != nullptr, "resample_images: bad arguments");
+    return resample_impl(src, src_bytes, desc_host, desc_dev, dst, nullptr, 0, B, S, kernel, vmin, vmax, mean3, std3, stream);
+}
+
+int vitk_resample_patches(const unsigned char* src, int64_t src_bytes, const vitk_resample_desc* desc_host,
+                          const vitk_resample_desc* desc_dev, void* patches, int patch, int B, int S, int kernel, float vmin, float vmax,
+                          const float* mean3, const float* std3, void* stream) {
+    VITK_REQUIRE(patches != nullptr && patch > 0 && patch % 8 == 0 && S % patch == 0,
+                 "resample_patches: the patch size %d must be a multiple of 8 that divides the image size %d", patch, S);
+    return resample_impl(src, src_bytes, desc_host, desc_dev, nullptr, (bf16_t*)patches, patch, B, S, kernel, vmin, vmax, mean3, std3, stream);
+}
+
+}  // extern "C"
+
+static int resample_impl(const unsigned char* src, int64_t src_bytes, const vitk_resample_desc* desc_host,
+                         const vitk_resample_desc* desc_dev, float* dst, bf16_t* patches, int patch, int B, int S, int kernel, float vmin,
+                         float vmax, const float* mean3, const float* std3, void* stream) {
+    VITK_REQUIRE(src && desc_host && desc_dev && (dst || patches) && B > 0 && src_bytes > 0, "resample_images: bad arguments");
     VITK_REQUIRE(S > 0 && S % 4 == 0 && S <= 1024, "resample_images: output size %d must be a multiple of 4, at most 1024", S);
     VITK_REQUIRE(kernel == 0 || kernel == 1, "resample_images: kernel must be 0 (triangle / BILINEAR) or 1 (keyscubic / BICUBIC)");
     VITK_REQUIRE((mean3 == nullptr) == (std3 == nullptr), "resample_images: mean and std go together");
-    VITK_REQUIRE(vitk_aligned(dst, 16) && vitk_aligned(desc_dev, 8), "resample_images: dst / desc alignment");
+    VITK_REQUIRE(vitk_aligned(dst, 16) && vitk_aligned(patches, 16) && vitk_aligned(desc_dev, 8), "resample_images: dst / desc alignment");
     int max_box_w = 1;
     for (int b = 0; b < B; ++b) {
         const vitk_resample_desc& d = desc_host[b];
         VITK_REQUIRE(d.src_h > 0 && d.src_w > 0 && d.src_offset >= 0 && d.src_offset + (int64_t)d.src_h * d.src_w * 3 <= src_bytes,
                      "resample_images: image %d (%d x %d at byte %lld) does not fit the %lld source bytes", b, d.src_h, d.src_w,
                      (long long)d.src_offset, (long long)src_bytes);
-        VITK_REQUIRE(d.box_h > 0 && d.box_w > 0 && d.box_y >= 0 && d.box_x >= 0 && d.box_y + d.box_h <= d.src_h && d.box_x + d.box_w <= d.src_w,
+        VITK_REQUIRE(d.box_h > 0 && d.box_w > 0 && d.box_y >= 0 && d.box_x >= 0 && (int64_t)d.box_y + d.box_h <= d.src_h &&
+                         (int64_t)d.box_x + d.box_w <= d.src_w,
                      "resample_images: image %d: box %d x %d at (%d, %d) outside the %d x %d image", b, d.box_h, d.box_w, d.box_y, d.box_x,
                      d.src_h, d.src_w);
         VITK_REQUIRE(d.out_h > 0 && d.out_w > 0 && d.box_w <= 12288, "resample_images: image %d: bad output size or a box wider than 12288", b);
@@ -244,9 +360,11 @@ int vitk_resample_images(const unsigned char* src, int64_t src_bytes, const vitk
     if (int rc_ = vitk_lds_once(once, (const void*)resample_kernel_rows, ((size_t)RESAMPLE_MAX_TAPS + 12288 * 3) * sizeof(float), "resample_images"))
         return rc_;
     resample_kernel_rows<<<B * S, 256, smem, (hipStream_t)stream>>>(src, desc_dev, dst, S, kernel, vmax - vmin, vmin, normalise, m0, m1, m2, s0,
-                                                                    s1, s2);
+                                                                    s1, s2, patches, patch, (long long)src_bytes, max_box_w);
     return vitk_check_launch("resample_images");
 }
+
+extern "C" {
 
 int vitk_preprocess_images(const void* src, int src_is_u8, const unsigned char* flip, float* dst, int B, int H, int W, int src_h,
                            int src_w, int top, int left, float vmin, float vmax, const float* mean3, const float* std3,
@@ -272,6 +390,32 @@ int vitk_preprocess_images(const void* src, int src_is_u8, const unsigned char* 
         images_to_nchw_kernel<false><<<(int)g, 256, 0, (hipStream_t)stream>>>(src, flip, dst, B, H, W, src_h, src_w, top, left, scale,
                                                                             vmin, normalise, m0, m1, m2, s0, s1, s2);
     return vitk_check_launch("preprocess_images");
+}
+
+int vitk_preprocess_patches(const void* src, int src_is_u8, const unsigned char* flip, void* dst, int patch, int B, int H, int W, int src_h,
+                            int src_w, int top, int left, float vmin, float vmax, const float* mean3, const float* std3, void* stream) {
+    VITK_REQUIRE(src && dst && B > 0 && H > 0 && W > 0, "preprocess_patches: bad arguments");
+    VITK_REQUIRE(patch > 0 && patch % 8 == 0 && H % patch == 0 && W % patch == 0,
+                 "preprocess_patches: the patch size %d must be a multiple of 8 that divides the %d x %d window", patch, H, W);
+    VITK_REQUIRE(top >= 0 && left >= 0 && (int64_t)top + H <= src_h && (int64_t)left + W <= src_w,
+                 "preprocess_patches: window %dx%d at (%d,%d) outside the %dx%d source", H, W, top, left, src_h, src_w);
+    VITK_REQUIRE((mean3 == nullptr) == (std3 == nullptr), "preprocess_patches: mean and std go together");
+    VITK_REQUIRE(vitk_aligned(dst, 16) && vitk_aligned(src, src_is_u8 ? 4 : 16), "preprocess_patches: src / dst alignment");
+    const int normalise = mean3 != nullptr;
+    const float m0 = normalise ? mean3[0] : 0.f, m1 = normalise ? mean3[1] : 0.f, m2 = normalise ? mean3[2] : 0.f;
+    const float s0 = normalise ? std3[0] : 1.f, s1 = normalise ? std3[1] : 1.f, s2 = normalise ? std3[2] : 1.f;
+    VITK_REQUIRE(s0 != 0.f && s1 != 0.f && s2 != 0.f, "preprocess_patches: std must be non-zero");
+    const float scale = vmax - vmin;
+    const size_t items = (size_t)B * H * (W / 8);
+    size_t g = (items + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (src_is_u8)
+        images_to_patches_kernel<true><<<(int)g, 256, 0, (hipStream_t)stream>>>(src, flip, (bf16_t*)dst, B, H, W, src_h, src_w, top, left, patch,
+                                                                              scale, vmin, normalise, m0, m1, m2, s0, s1, s2);
+    else
+        images_to_patches_kernel<false><<<(int)g, 256, 0, (hipStream_t)stream>>>(src, flip, (bf16_t*)dst, B, H, W, src_h, src_w, top, left, patch,
+                                                                               scale, vmin, normalise, m0, m1, m2, s0, s1, s2);
+    return vitk_check_launch("preprocess_patches");
 }
 
 }  // extern "C"

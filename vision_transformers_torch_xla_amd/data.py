@@ -56,8 +56,8 @@ def sample_inception_box(h: int, w: int, rng: np.random.Generator, area=(0.08, 1
             bw = int(np.rint(bh * ar))
         if not (lo_area <= bw * bh <= hi_area) or bw > w or bh > h or bw <= 0 or bh <= 0:
             continue
-        y = int(rng.integers(0, h - bh + 1)) if bh < h else 0
-        x = int(rng.integers(0, w - bw + 1)) if bw < w else 0
+        y = int(rng.integers(0, h - bh)) if bh < h else 0          # the origin is uniform over [0, H - h), as TensorFlow's
+        x = int(rng.integers(0, w - bw)) if bw < w else 0          # GenerateRandomCrop draws it (Uniform(H - h))
         return y, x, bh, bw
     return 0, 0, h, w
 
@@ -66,6 +66,22 @@ def resize_small_size(h: int, w: int, size: int):
     """(new_h, new_w) of resize_small(size) (ops_image.py:104-111): float32 products, ties to even as tf.round"""
     scale = np.float32(size) / max(np.float32(1.0), np.float32(min(h, w)))
     return int(np.rint(np.float32(h) * scale)), int(np.rint(np.float32(w) * scale))
+
+
+MAX_SOURCE_WIDTH = 12288        # widest crop box one workgroup of the resample kernel keeps in LDS
+MAX_ROW_REDUCTION = 100         # largest source-rows : output-rows ratio whose filter taps fit the kernel's table (cubic: 127)
+
+
+def fit_for_resample(im, size):
+    """An image the resample kernel cannot take whole - wider than MAX_SOURCE_WIDTH, or so tall that one output row of `size`
+    would need more filter taps than the kernel holds - is halved with a 2 x 2 box average (rounded to nearest) until it fits,
+    instead of aborting the epoch; every other image is returned as it is.  (The reference has no such limit: its host resize
+    takes any size.  Such images - above 100 megapixels at size 224 - do not occur in ImageNet.)"""
+    while im.shape[1] > MAX_SOURCE_WIDTH or im.shape[0] > MAX_ROW_REDUCTION * size:
+        h, w = im.shape[0] // 2 * 2, im.shape[1] // 2 * 2
+        q = im[:h, :w].astype(np.uint16)
+        im = ((q[0::2, 0::2] + q[1::2, 0::2] + q[0::2, 1::2] + q[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    return im
 
 
 def pack_images(images):
@@ -165,12 +181,16 @@ class ResampleLoader:
       train=False  decode | resize_small(resize) | central_crop(size) | value_range(0, 1)   (main.py:275)
     followed by the ImageNet normalisation (datasets.py:249-252).  Crop boxes and flips are drawn per epoch from
     numpy's Generator(seed + epoch) (datasets.py:258-261 seeds tf.data the same way).  The packed pixels and the descriptors
-    cross PCIe through two pinned slots on a copy stream while the previous batch trains."""
+    cross PCIe through two pinned slots on a copy stream while the previous batch trains.
+    patch=p yields the model's bf16 patch matrix [B * (size/p)^2, 3 * p * p] instead of the fp32 batch (the same values the model
+    would form from it; for runs whose images nothing else touches between the loader and the model: evaluation, training
+    without Mixup / CutMix, which mix fp32 images)."""
 
     def __init__(self, batches, device, size=224, train=True, resize=256, flip_lr=True, value_range=(0.0, 1.0), normalize="imagenet",
-                 seed=None, length=None, method=None):
+                 seed=None, length=None, method=None, patch=None):
         if normalize not in ("imagenet", "none"):
             raise ValueError(f"normalize must be 'imagenet' or 'none', got {normalize!r}")
+        self.patch = patch
         self.batches, self.device, self.size, self.train, self.resize = batches, torch.device(device), int(size), train, int(resize)
         self.flip_lr, self.value_range, self.normalize, self.seed, self._length = flip_lr, value_range, normalize, seed, length
         self.method = method or ("triangle" if train else "keyscubic")      # BILINEAR for the inception crop, BICUBIC for resize_small
@@ -185,6 +205,7 @@ class ResampleLoader:
             self.batches.set_epoch(epoch)
 
     def _stage(self, slot, images, labels):
+        images = [fit_for_resample(im, self.size) for im in images]
         flat, offs = pack_images(images)
         desc = (train_descriptors(images, offs, self.size, self._rng, self.flip_lr) if self.train
                 else eval_descriptors(images, offs, self.resize, self.size))
@@ -213,8 +234,9 @@ class ResampleLoader:
     def __iter__(self):
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
-        self._epoch += 1
+        # the draws of epoch e come from Generator(seed + e); without set_epoch the counter advances by itself
         self._rng = np.random.default_rng((self.seed if self.seed is not None else 0) + self._epoch)
+        self._epoch += 1
         mean, std = (IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD) if self.normalize == "imagenet" else (None, None)
         it = iter(self.batches)
         slot = 0
@@ -233,7 +255,8 @@ class ResampleLoader:
             cur.wait_event(ev)
             for t in (pix, dd, lab):
                 t.record_stream(cur)
-            yield ops.resample_images(pix, desc, self.size, kernel=self.method, value_range=self.value_range, mean=mean, std=std, desc_dev=dd), lab
+            yield ops.resample_images(pix, desc, self.size, kernel=self.method, value_range=self.value_range, mean=mean, std=std, desc_dev=dd,
+                                      patch=self.patch), lab
 
 
 class DeviceLoader:
@@ -245,7 +268,8 @@ class DeviceLoader:
     fair coin per sample (ops_image.py:69-82) from a generator seeded with ``seed + epoch`` (datasets.py:258-261).
     """
 
-    def __init__(self, batches, device, flip_lr=False, value_range=(0.0, 1.0), normalize="imagenet", crop=None, seed=None, length=None):
+    def __init__(self, batches, device, flip_lr=False, value_range=(0.0, 1.0), normalize="imagenet", crop=None, seed=None, length=None, patch=None):
+        self.patch = patch              # yield the model's bf16 patch matrix instead of the fp32 batch (see ResampleLoader)
         if normalize not in ("imagenet", "none"):
             raise ValueError(f"normalize must be 'imagenet' or 'none', got {normalize!r}")
         self.batches = batches
@@ -295,9 +319,9 @@ class DeviceLoader:
     def __iter__(self):
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
-        self._epoch += 1
-        self._gen = torch.Generator()
+        self._gen = torch.Generator()           # epoch e flips with Generator(seed + e); without set_epoch the counter advances by itself
         self._gen.manual_seed((self.seed if self.seed is not None else 0) + self._epoch)
+        self._epoch += 1
         mean, std = (IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD) if self.normalize == "imagenet" else (None, None)
         it = iter(self.batches)
         pending, slot = None, 0
@@ -320,5 +344,6 @@ class DeviceLoader:
             window = None
             if self.crop is not None:
                 window = central_crop_window(img_dev.shape[1], img_dev.shape[2], self.crop)
-            samples = ops.preprocess_images(img_dev, flip=flip_dev, window=window, value_range=self.value_range, mean=mean, std=std)
+            samples = ops.preprocess_images(img_dev, flip=flip_dev, window=window, value_range=self.value_range, mean=mean, std=std,
+                                            patch=self.patch)
             yield samples, lab_dev

@@ -81,7 +81,7 @@ class GraphedStep:
         core = self.core
         if self.x is None:
             self.x, self.y = samples.clone(), targets.clone()
-            core.begin_static_droppath(samples.shape[0], samples.device)
+            core.begin_static_droppath(targets.shape[0], samples.device)      # samples may be a patch matrix: count the labels
         if not self._fits(samples, targets):
             output = self.model(samples)            # another batch size draws its own factors (forward checks the table's size)
             loss = self.criterion(output, targets)
@@ -106,13 +106,32 @@ class GraphedStep:
             return output, loss
         self.graph.replay()
         GraphedStep.total_replays += 1
+        # a replay runs no Python: what the eager backward does on the host besides launching kernels is done here - every
+        # parameter's .grad is the view of the flat gradient buffer the kernels just wrote, and the buffer counts as valid - so a
+        # reader of p.grad (torch's clip_grad_norm_, a gradient logger, the per-parameter path of the optimizer) sees this step
+        for n, p in zip(core._pnames, core._plist):
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != core._gview[n].data_ptr()):
+                p.grad = core._gview[n]
+        core._grad_valid = True
         # the graph's outputs are overwritten by the next replay: hand out copies
         output = tuple(o.clone() for o in self.output) if isinstance(self.output, tuple) else self.output.clone()
         return output, self.loss.clone()
 
+    def pause(self):
+        """leave the replayable mode (the model draws its own stochastic-depth factors again) but keep the captured graph and the
+        table it reads: resume() continues with both in the next epoch"""
+        self._parked = self.core._static_drop
+        self.core.end_static_droppath()
+
+    def resume(self):
+        if getattr(self, "_parked", None) is not None:
+            self.core._static_drop = self._parked        # the same table at the same address: the captured graph reads it
+            self._parked = None
+
     def close(self):
         self.core.end_static_droppath()
         self.graph = None
+        self._parked = None
 
 
 def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loader: Iterable,
@@ -129,7 +148,15 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
     header = f"Epoch: [{epoch}]"
     reducer = getattr(model, "reducer", None)
     optimizer.zero_grad()
-    graphed = GraphedStep(model, criterion) if GraphedStep.wanted(model, update_freq) else None      # VITK_GRAPH_STEP=1
+    graphed = None
+    if GraphedStep.wanted(model, update_freq):      # VITK_GRAPH_STEP=1: the captured step is kept on the model from epoch to epoch
+        holder = _core_model(model)                 # (its deep copies - an EMA model - are rebuilt from scratch and do not inherit it)
+        graphed = getattr(holder, "_vitk_graphed_step", None)
+        if graphed is None or graphed.criterion is not criterion or graphed.model is not model:
+            graphed = GraphedStep(model, criterion)
+            holder._vitk_graphed_step = graphed
+        else:
+            graphed.resume()
 
     try:
         for data_iter_step, (samples, targets) in enumerate(data_loader):
@@ -178,7 +205,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             if data_iter_step % log_freq == 0 or data_iter_step < 5:
                 metric_logger.update(loss=loss.detach())
                 if class_acc is not None:
-                    metric_logger.meters["class_acc"].update(class_acc, n=samples.size(0))
+                    metric_logger.meters["class_acc"].update(class_acc, n=targets.size(0))
                 metric_logger.update(lr=optimizer.param_groups[0]["lr"])
             if log_writer is not None:          # a per-step host log is the caller's choice: it costs one sync per step
                 lv = metric_logger.meters["loss"].value if metric_logger.meters["loss"].count else float("nan")
@@ -186,7 +213,7 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
 
     finally:
         if graphed is not None:       # also when the loop raises: the model must not keep reading the static DropPath table
-            graphed.close()
+            graphed.pause()
     metric_logger.flush()
     if "loss" in metric_logger.meters and not math.isfinite(metric_logger.meters["loss"].global_avg):
         print("Loss is {}, stopping training".format(metric_logger.meters["loss"].global_avg))
@@ -209,7 +236,7 @@ def evaluate(data_loader, model, device, use_amp=False, tpu: bool = False):
         output = model(images)
         loss = criterion(output, target)
         acc1, acc5 = utils.accuracy(output, target, topk=(1, 5))
-        bs = images.shape[0]
+        bs = target.shape[0]
         metric_logger.update(loss=loss)
         metric_logger.meters["acc1"].update(acc1, n=bs)
         metric_logger.meters["acc5"].update(acc5, n=bs)

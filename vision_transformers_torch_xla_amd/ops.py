@@ -522,10 +522,14 @@ def mixup_targets(target, num_classes: int, lam: float, on_value: float, off_val
 
 
 # ------------------------------------------------------------------------------------------ input pipeline tail
-def preprocess_images(src, flip=None, out=None, window=None, value_range=(0.0, 1.0), mean=None, std=None):
+def preprocess_images(src, flip=None, out=None, window=None, value_range=(0.0, 1.0), mean=None, std=None, patch=None):
     """src uint8 / fp32 [B, Hs, Ws, 3] on the GPU -> fp32 NCHW [B, 3, H, W]: flip_lr for flip[b] != 0 (uint8 [B]), value_range,
-    HWC -> CHW, (v - mean) / std; window = (top, left, H, W) crops every image (default: the whole image)."""
+    HWC -> CHW, (v - mean) / std; window = (top, left, H, W) crops every image (default: the whole image).
+    patch = p: the result is the model's bf16 patch matrix [B * (H/p) * (W/p), 3 * p * p] instead (what the patch-embedding GEMM
+    reads; bit-identical to im2col_patches of the fp32 batch, without that batch being written and read in between)."""
     import ctypes
+    if patch is not None:
+        return _preprocess_patches(src, flip, out, window, value_range, mean, std, int(patch))
     if src.dtype not in (torch.uint8, f32):
         raise _lib.VitkError(f"src: expected uint8 or float32 images, got {src.dtype}")
     _chk(src, src.dtype, "src")
@@ -553,12 +557,44 @@ def preprocess_images(src, flip=None, out=None, window=None, value_range=(0.0, 1
     return out
 
 
+def _preprocess_patches(src, flip, out, window, value_range, mean, std, patch):
+    import ctypes
+    if src.dtype not in (torch.uint8, f32):
+        raise _lib.VitkError(f"src: expected uint8 or float32 images, got {src.dtype}")
+    _chk(src, src.dtype, "src")
+    if src.dim() != 4 or src.shape[3] != 3:
+        raise _lib.VitkError(f"src: expected [B, H, W, 3], got {tuple(src.shape)}")
+    B, Hs, Ws, _ = src.shape
+    top, left, H, W = window if window is not None else (0, 0, Hs, Ws)
+    if patch <= 0 or patch % 8 or H % patch or W % patch:
+        raise _lib.VitkError(f"patch size {patch} must be a multiple of 8 that divides the {H} x {W} window")
+    if flip is not None:
+        _chk(flip, torch.uint8, "flip")
+        if flip.numel() != B:
+            raise _lib.VitkError(f"flip: expected {B} flags, got {flip.numel()}")
+    shape = (B * (H // patch) * (W // patch), 3 * patch * patch)
+    if out is None:
+        out = torch.empty(shape, dtype=bf16, device=src.device)
+    else:
+        _chk(out, bf16, "out")
+        if tuple(out.shape) != shape:
+            raise _lib.VitkError(f"out: expected {shape}, got {tuple(out.shape)}")
+    if (mean is None) != (std is None):
+        raise _lib.VitkError("mean and std go together")
+    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    s = (ctypes.c_float * 3)(*std) if std is not None else None
+    check(_lib.load().vitk_preprocess_patches(_ptr(src), int(src.dtype == torch.uint8), _ptr(flip), _ptr(out), patch, B, int(H), int(W), Hs, Ws,
+                                              int(top), int(left), float(value_range[0]), float(value_range[1]), m, s, _stream()),
+          "preprocess_patches")
+    return out
+
+
 RESAMPLE_DESC = np.dtype([("src_offset", "<i8"), ("src_h", "<i4"), ("src_w", "<i4"), ("box_y", "<i4"), ("box_x", "<i4"), ("box_h", "<i4"),
                           ("box_w", "<i4"), ("out_h", "<i4"), ("out_w", "<i4"), ("win_y", "<i4"), ("win_x", "<i4"), ("flip", "<i4"),
                           ("reserved", "<i4")])          # vitk_resample_desc (include/vitk.h), 56 bytes
 
 
-def resample_images(src, desc, size, kernel="triangle", out=None, value_range=(0.0, 1.0), mean=None, std=None, desc_dev=None):
+def resample_images(src, desc, size, kernel="triangle", out=None, value_range=(0.0, 1.0), mean=None, std=None, desc_dev=None, patch=None):
     """Decoded uint8 images of different sizes, packed one after the other in `src` (1-D uint8 on the GPU), -> fp32 NCHW
     [B, 3, size, size]: per image the box desc['box_*'] is resized to desc['out_*'] with tf.image.resize(antialias=True)'s
     arithmetic ('triangle' = BILINEAR, 'keyscubic' = BICUBIC) and the size x size window at desc['win_*'] of the result is
@@ -575,16 +611,31 @@ def resample_images(src, desc, size, kernel="triangle", out=None, value_range=(0
     _chk(desc_dev, torch.uint8, "desc_dev")
     if desc_dev.numel() != B * RESAMPLE_DESC.itemsize:
         raise _lib.VitkError(f"desc_dev: expected {B * RESAMPLE_DESC.itemsize} bytes, got {desc_dev.numel()}")
+    if (mean is None) != (std is None):
+        raise _lib.VitkError("mean and std go together")
+    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    s = (ctypes.c_float * 3)(*std) if std is not None else None
+    if patch is not None:          # the model's bf16 patch matrix instead of the fp32 NCHW batch (see preprocess_images)
+        patch = int(patch)
+        if patch <= 0 or patch % 8 or size % patch:
+            raise _lib.VitkError(f"patch size {patch} must be a multiple of 8 that divides the image size {size}")
+        shape = (B * (size // patch) ** 2, 3 * patch * patch)
+        if out is None:
+            out = torch.empty(shape, dtype=bf16, device=src.device)
+        else:
+            _chk(out, bf16, "out")
+            if tuple(out.shape) != shape:
+                raise _lib.VitkError(f"out: expected {shape}, got {tuple(out.shape)}")
+        check(_lib.load().vitk_resample_patches(_ptr(src), int(src.numel()), desc.ctypes.data, _ptr(desc_dev), _ptr(out), patch, B, int(size),
+                                                0 if kernel == "triangle" else 1, float(value_range[0]), float(value_range[1]), m, s,
+                                                _stream()), "resample_patches")
+        return out
     if out is None:
         out = torch.empty((B, 3, size, size), dtype=f32, device=src.device)
     else:
         _chk(out, f32, "out")
         if tuple(out.shape) != (B, 3, size, size):
             raise _lib.VitkError(f"out: expected {(B, 3, size, size)}, got {tuple(out.shape)}")
-    if (mean is None) != (std is None):
-        raise _lib.VitkError("mean and std go together")
-    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
-    s = (ctypes.c_float * 3)(*std) if std is not None else None
     check(_lib.load().vitk_resample_images(_ptr(src), int(src.numel()), desc.ctypes.data, _ptr(desc_dev), _ptr(out), B, int(size),
                                            0 if kernel == "triangle" else 1, float(value_range[0]), float(value_range[1]), m, s, _stream()),
           "resample_images")

@@ -140,6 +140,8 @@ class FusedAdamW(torch.optim.Optimizer):
             self._build_plan()
         self._steps += 1
         model = self._model
+        if model is not None and hasattr(model, "_await_transposes"):
+            model._await_transposes()            # the kernels below rewrite the bf16 weights a deferred transposition may still read
         for group, (ranges, loose) in zip(self.param_groups, self._plan):
             b1, b2 = group["betas"]
             kw = dict(lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"], step=self._steps,

@@ -223,11 +223,18 @@ class VisionTransformer(nn.Module):
             raise VitkError(f"head dim must be a multiple of 8 up to 96 (embed_dim={embed_dim}, heads={num_heads}: {embed_dim / num_heads:g})")
         if patch_size % 8 or img_size % patch_size:
             raise VitkError("patch_size must be a multiple of 8 and divide img_size")
-        if num_classes % 8:
-            raise VitkError("num_classes must be a multiple of 8 (MFMA GEMM alignment)")
+        if num_classes < 1:
+            raise VitkError("num_classes must be positive (a headless model is not implemented)")
         if embed_dim > 1024 or embed_dim % 8:
             raise VitkError("embed_dim must be a multiple of 8 and <= 1024 (LayerNorm kernel)")
         self.num_classes, self.global_pool, self.distilled = num_classes, global_pool, distilled
+        # The head GEMMs want a class count that is a multiple of 8 (16-byte rows of the bf16 operands).  Any other count - the
+        # reference's --nb_classes is free, and fine-tuning onto 37 or 100 classes is its stated use (main.py:653-674) - runs on
+        # ZERO-PADDED bf16 copies of the head weights (padding rows zero, padding bias entries zero): the padded logits are cut
+        # off before anything reads them, the padded columns of the logit gradient are zero, and the weight / bias gradients of the
+        # real rows are copied out of the padded product.  Parameters, gradients, optimizer state and state dicts keep timm's shapes.
+        self._cls_pad = (num_classes + 7) // 8 * 8
+        self._pad_head = self._cls_pad != num_classes
         self.num_features = self.head_hidden_size = self.embed_dim = embed_dim
         self.depth, self.num_heads, self.patch_size, self.in_chans = depth, num_heads, patch_size, in_chans
         self.num_prefix_tokens = 2 if distilled else 1
@@ -362,6 +369,7 @@ class VisionTransformer(nn.Module):
             torch.cuda.current_stream().wait_event(pending)
         self._wt = {}
         self._wpad = {}
+        self._hpad = {}
         self._wt_plan = None
         self._wt_plan_key = None
         self._wt_ready = None       # event behind a transposition that runs on the side stream; backward waits for it
@@ -401,9 +409,18 @@ class VisionTransformer(nn.Module):
             return
         if not self._flat["p"].is_cuda:
             raise VitkError("the model must be on the GPU (model.cuda()): libvitk is the only implementation")
+        self._await_transposes()
         ops.cast_f32_to_bf16(self._flat["p"], self._flat["b"])
         self._refresh_transposes()
         self._weights_version = key
+
+    def _await_transposes(self):
+        """A transposition that an optimizer step left on the side stream READS the bf16 weight buffer: whoever overwrites that
+        buffer next (another optimizer step with no backward in between, a load_state_dict followed by a forward pass) first
+        makes the current stream wait for it."""
+        if self._wt_ready is not None:
+            torch.cuda.current_stream().wait_event(self._wt_ready)
+            self._wt_ready = None
 
     def _build_views(self):
         """2-D views into the flat buffers: bf16 GEMM weights [out, in], the prefix-token table, the position table."""
@@ -461,12 +478,20 @@ class VisionTransformer(nn.Module):
         tile rounds leave empty; the next backward waits for `_wt_ready`."""
         key = (self._flat["b"].data_ptr(), str(self._flat["b"].device))
         H, hd, hp = self.num_heads, self.head_dim, self._hd_pad
+        cur = torch.cuda.current_stream()
+        if self._wt_ready is not None:           # a transposition still queued on the side stream reads the padded copies rewritten
+            cur.wait_event(self._wt_ready)       # below and writes the transposed ones: wait for it before touching either
+            self._wt_ready = None
         if getattr(self, "_wt_plan_key", None) != key:
             pairs = []
             self._wpad = {}
+            self._hpad = {}
             for n, src in self._wb.items():
                 if n == "patch_embed.proj.weight":      # the image needs no gradient
                     continue
+                if self._pad_head and n in ("head.weight", "head_dist.weight"):          # [C, D] -> [Cp, D], zero rows behind
+                    src = self._hpad[n] = torch.zeros((self._cls_pad, src.shape[1]), dtype=bf16, device=src.device)
+                    self._hpad[n[:-6] + "bias"] = torch.zeros(self._cls_pad, dtype=f32, device=src.device)
                 if self._pad_heads and n.endswith("attn.qkv.weight"):        # [3 H hd, D] -> [3 H hp, D], zero rows between
                     src = self._wpad[n] = torch.zeros((3 * H * hp, src.shape[1]), dtype=bf16, device=src.device)
                     self._wpad[n[:-6] + "bias"] = torch.zeros(3 * H * hp, dtype=f32, device=src.device)
@@ -487,10 +512,11 @@ class VisionTransformer(nn.Module):
                     dst.view(3 * H, hp)[:, :hd].copy_(named[n].detach().view(3 * H, hd))
                 else:
                     dst.view(-1, H, hp)[:, :, :hd].copy_(self._wb[n].view(-1, H, hd))
-        cur = torch.cuda.current_stream()
-        if self._wt_ready is not None:           # a transposition still queued on the side stream writes the same copies
-            cur.wait_event(self._wt_ready)
-            self._wt_ready = None
+        if self._pad_head:
+            named = dict(zip(self._pnames, self._plist))
+            C = self.num_classes
+            for n, dst in self._hpad.items():
+                dst[:C].copy_(self._wb[n] if n.endswith("weight") else named[n].detach())
         # (a captured step that is replayed does not see events recorded outside its graph: no deferral then)
         side = self._wgrad_stream() if (defer and self._static_drop is None) else None
         if side is None:
@@ -576,31 +602,47 @@ class VisionTransformer(nn.Module):
     def end_static_droppath(self):
         self._static_drop = None
 
+    def is_patch_matrix(self, x) -> bool:
+        """x is the bf16 patch matrix [B * num_patches, in_chans * patch^2] the device input pipeline writes for the model
+        (ops.preprocess_images / ops.resample_images with patch=...) rather than an image batch"""
+        return (x.dim() == 2 and x.dtype == bf16 and x.shape[1] == self.in_chans * self.patch_size ** 2 and x.shape[0] > 0
+                and x.shape[0] % self.num_patches == 0)
+
     def forward(self, x: torch.Tensor):
+        """x: the image batch [B, C, H, W] (fp32, as datasets.py:301-314 hands it to the reference's model) - or the bf16 patch
+        matrix of that batch (is_patch_matrix), which the patch-embedding GEMM reads as it is."""
         if not x.is_cuda:
             raise VitkError("VisionTransformer.forward: input must be a GPU tensor; this model has no CPU implementation")
-        if x.dim() != 4 or x.shape[1] != self.in_chans or x.shape[2] != self.patch_embed.img_size[0] or x.shape[3] != self.patch_embed.img_size[1]:
-            raise VitkError(f"input shape {tuple(x.shape)} does not match [B,{self.in_chans},{self.patch_embed.img_size[0]},{self.patch_embed.img_size[1]}]")
-        if x.dtype != f32 or not x.is_contiguous():
-            x = x.float().contiguous()
+        if self.is_patch_matrix(x):
+            if not x.is_contiguous():
+                x = x.contiguous()
+            batch = x.shape[0] // self.num_patches
+        else:
+            if x.dim() != 4 or x.shape[1] != self.in_chans or x.shape[2] != self.patch_embed.img_size[0] or x.shape[3] != self.patch_embed.img_size[1]:
+                raise VitkError(f"input shape {tuple(x.shape)} does not match [B,{self.in_chans},{self.patch_embed.img_size[0]},{self.patch_embed.img_size[1]}]"
+                                f" (or a bf16 patch matrix [B*{self.num_patches},{self.in_chans * self.patch_size ** 2}])")
+            if x.dtype != f32 or not x.is_contiguous():
+                x = x.float().contiguous()
+            batch = x.shape[0]
         self._sync_weights()
-        if self._static_drop is not None and self.training and self._static_drop["B"] == x.shape[0]:
+        if self._static_drop is not None and self.training and self._static_drop["B"] == batch:
             scales = self._static_drop["scales"]         # refreshed by refresh_static_droppath(), never drawn in here
         else:
-            scales = self._draw_drop_scales(x.shape[0], x.device)
+            scales = self._draw_drop_scales(batch, x.device)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist):
             return _ViTFunction.apply(x, self, scales, *self._plist)
         outs, _ = self._forward_impl(x, scales, save=False)
         return outs[0] if len(outs) == 1 else tuple(outs)
 
     def _forward_impl(self, img, scales, save):
-        B = img.shape[0]
         N, D, H, npre, P = self.num_tokens, self.embed_dim, self.num_heads, self.num_prefix_tokens, self.num_patches
+        as_patches = img.dim() == 2          # the bf16 patch matrix itself (see forward)
+        B = img.shape[0] // P if as_patches else img.shape[0]
         M = B * N
         wb = self._wb
         wa = self._wpad if self._pad_heads else wb      # qkv / proj weights as the attention branch reads them
         scale = self.head_dim ** -0.5
-        patches = ops.im2col_patches(img, self.patch_size)
+        patches = img if as_patches else ops.im2col_patches(img, self.patch_size)
         x = torch.empty((M, D), dtype=bf16, device=img.device)
         ops.gemm_nt(patches, wb["patch_embed.proj.weight"], epilogue=EPI_PATCH, bias=self.patch_embed.proj.bias, out=x,
                     pos=self._pos2d, patches=P, prefix=npre)
@@ -654,22 +696,30 @@ class VisionTransformer(nn.Module):
                 layers.append((x, m1, r1, y1, qkv, o, lse, x2, m2, r2, y2, h, a, s1, s2))
             x = x3
         tail = {}
+
+        def head_fwd(feat, wname, lin):
+            """logits [B, num_classes] fp32; a class count that is not a multiple of 8 goes through the zero-padded copies"""
+            if not self._pad_head:
+                return ops.gemm_nt(feat, wb[wname], epilogue=EPI_BIAS_F32, bias=lin.bias)
+            padded = ops.gemm_nt(feat, self._hpad[wname], epilogue=EPI_BIAS_F32, bias=self._hpad[wname[:-6] + "bias"])
+            return padded[:, :self.num_classes].contiguous()
+
         if self.global_pool == "avg":
             pooled = ops.pool_avg_fwd(x, B, N, D, npre)
             f, mf, rf = ops.layernorm_fwd(pooled, self.fc_norm.weight, self.fc_norm.bias, self.fc_norm.eps)
-            logits = ops.gemm_nt(f, wb["head.weight"], epilogue=EPI_BIAS_F32, bias=self.head.bias)
+            logits = head_fwd(f, "head.weight", self.head)
             outs = [logits]
             tail = dict(pooled=pooled, f=f, mf=mf, rf=rf)
         else:
             c = ops.gather_rows(x, B, N, D, 0)
             f, mf, rf = ops.layernorm_fwd(c, self.norm.weight, self.norm.bias, self.norm.eps)
-            logits = ops.gemm_nt(f, wb["head.weight"], epilogue=EPI_BIAS_F32, bias=self.head.bias)
+            logits = head_fwd(f, "head.weight", self.head)
             outs = [logits]
             tail = dict(c=c, f=f, mf=mf, rf=rf)
             if self.distilled:
                 c2 = ops.gather_rows(x, B, N, D, 1)
                 f2, mf2, rf2 = ops.layernorm_fwd(c2, self.norm.weight, self.norm.bias, self.norm.eps)
-                logits2 = ops.gemm_nt(f2, wb["head_dist.weight"], epilogue=EPI_BIAS_F32, bias=self.head_dist.bias)
+                logits2 = head_fwd(f2, "head_dist.weight", self.head_dist)
                 tail.update(c2=c2, f2=f2, mf2=mf2, rf2=rf2)
                 if self.distilled_training and self.training:
                     outs = [logits, logits2]                                 # deit.py:114-116
@@ -724,9 +774,19 @@ class VisionTransformer(nn.Module):
         tail = saved["tail"]
 
         def head_bwd(dlog, f, wname, bname, acc_):
-            dl = ops.cast_f32_to_bf16(dlog.contiguous())
-            ops.gemm_tn(dl, f, g[wname], dbias=g[bname], accumulate=acc_, ws=ws)
-            return ops.gemm_nt(dl, wt[wname])                               # [B, D]
+            if not self._pad_head:
+                dl = ops.cast_f32_to_bf16(dlog.contiguous())
+                ops.gemm_tn(dl, f, g[wname], dbias=g[bname], accumulate=acc_, ws=ws)
+                return ops.gemm_nt(dl, wt[wname])                           # [B, D]
+            # padded class count: zero columns behind the real ones, products in the padded shape, real rows copied (or added) across
+            C, Cp = self.num_classes, self._cls_pad
+            dl = torch.zeros((dlog.shape[0], Cp), dtype=bf16, device=dlog.device)
+            dl[:, :C].copy_(dlog)                                           # fp32 -> bf16, round to nearest even
+            tw = torch.empty((Cp, f.shape[1]), dtype=f32, device=dlog.device)
+            tb = torch.empty(Cp, dtype=f32, device=dlog.device)
+            ops.gemm_tn(dl, f, tw, dbias=tb, accumulate=False, ws=ws)
+            (g[wname].add_(tw[:C]), g[bname].add_(tb[:C])) if acc_ else (g[wname].copy_(tw[:C]), g[bname].copy_(tb[:C]))
+            return ops.gemm_nt(dl, wt[wname])                               # wt: the transposed PADDED copy [D, Cp]
 
         if self.global_pool == "avg":
             df = head_bwd(douts[0], tail["f"], "head.weight", "head.bias", acc)
