@@ -185,8 +185,8 @@ def test_graphed_step_survives_epochs_and_fills_param_grads(device, monkeypatch)
     # one more replayed step by hand: gradients through p.grad
     held.resume()
     x, y = data[0]
-    opt.zero_grad()
-    assert all(p.grad is None for p in m.parameters())
+    m.zero_grad(set_to_none=True)            # what a caller's torch-style zero_grad leaves behind: no .grad at all
+    assert all(p.grad is None for p in m.parameters()) and not m._grad_valid
     held.step(x.to(device), y.to(device))
     held.pause()
     assert m._grad_valid and all(p.grad is not None and p.grad.data_ptr() == m._gview[n].data_ptr() for n, p in m.named_parameters())
