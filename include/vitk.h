@@ -272,6 +272,21 @@ int vitk_cutmix_batch(float* x, int B, int C, int H, int W, int yl, int yh, int 
 /* soft targets fp32 [B,C]: one_hot(target, on, off)*lam + one_hot(target.flip(0), on, off)*(1-lam) (timm mixup_target) */
 int vitk_mixup_targets(const int64_t* target, float* out, int ldo, int B, int C, float lam, float one_minus_lam,
                        float on_value, float off_value, void* stream);
+/* timm.data.Mixup modes 'elem' and 'pair' (Mixup._mix_elem / _mix_pair; --mixup_mode is forwarded at main.py:229, 628): one
+ * lambda, kind and box per sample.  Sample b is mixed with the ORIGINAL of sample B-1-b, in place (both samples of a pair are
+ * read before either is written).  params_host is validated before the launch, the kernel reads the caller's device copy. */
+typedef struct vitk_mixup_sample {
+    int kind;              /* 0 untouched (lambda = 1), 1 mixup, 2 cutmix */
+    float lam;             /* mixup: weight of the sample itself */
+    float one_minus_lam;   /* mixup: weight of its partner (formed by the caller, in the precision the reference forms it) */
+    int yl, yh, xl, xh;    /* cutmix: rows [yl, yh) and columns [xl, xh) are taken from the partner */
+    int reserved;
+} vitk_mixup_sample;
+int vitk_mixup_elem(float* x, int B, int C, int H, int W, const vitk_mixup_sample* params_host, const vitk_mixup_sample* params_dev,
+                    void* stream);
+/* soft targets with one lambda per sample (fp32 [B] on the device): row b = one_hot(target[b])*lam[b] + one_hot(target[B-1-b])*(1-lam[b]) */
+int vitk_mixup_targets_elem(const int64_t* target, float* out, int ldo, int B, int C, const float* lam_rows, float on_value,
+                            float off_value, void* stream);
 
 /* ---- losses on fp32 logits [B,C] with leading dim ld.  loss_rows fp32 [B] per-sample loss, dlogits fp32 [B,C]
  * already scaled by grad_scale (= upstream grad / B for 'mean').

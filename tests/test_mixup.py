@@ -60,11 +60,44 @@ def test_oracle_properties():
     assert torch.equal(x2[:, :, mask], x[:, :, mask])
 
 
+@pytest.mark.parametrize("mode", ["elem", "pair"])
+@pytest.mark.parametrize("mix,cut", [(0.8, 1.0), (0.8, 0.0), (0.0, 1.0)])
+def test_per_sample_host_plan_matches_oracle(mode, mix, cut):
+    """modes 'elem' / 'pair': same numpy seed -> the plan the host hands to the kernel describes exactly what the oracle's loops do
+    (kinds, lambdas, boxes, the lambdas of the soft targets)"""
+    from vision_transformers_torch_xla_amd import ops
+    M = _host()
+    B, C = 8, 10
+    m = M.Mixup(mixup_alpha=mix, cutmix_alpha=cut, prob=0.8, switch_prob=0.5, mode=mode, label_smoothing=0.1, num_classes=C)
+    g = torch.Generator().manual_seed(3)
+    for it in range(6):
+        x = torch.randn(B, 3, 32, 32, generator=g)
+        y = torch.randint(0, C, (B,), generator=g)
+        np.random.seed(50 + it)
+        want_x, want_t, want_lam = RM.mix_per_sample(x, y, mode, mix, cut, 0.8, 0.5, C, 0.1)
+        np.random.seed(50 + it)
+        prm, lam_rows = m._sample_plan(x.shape)
+        assert prm.dtype == ops.MIXUP_SAMPLE and prm.itemsize == 32 and lam_rows.dtype == np.float32
+        assert np.array_equal(lam_rows, want_lam.astype(np.float32))
+        # the plan applied with plain torch on the CPU = the oracle's mixed batch
+        out = x.clone()
+        for b in range(B):
+            k, lam, oml, yl, yh, xl, xh, _ = prm[b].tolist()
+            if k == 1:
+                out[b] = x[b] * lam + x[B - 1 - b] * oml
+            elif k == 2:
+                out[b][:, yl:yh, xl:xh] = x[B - 1 - b][:, yl:yh, xl:xh]
+        assert torch.equal(out, want_x)
+        if mode == "pair":
+            assert all(prm[b] == prm[B - 1 - b] for b in range(B)) and np.array_equal(lam_rows, lam_rows[::-1])
+        assert torch.allclose(want_t.sum(1), torch.ones(B), atol=1e-6)
+
+
 def test_rejects_other_modes_and_odd_batches():
     from vision_transformers_torch_xla_amd._lib import VitkError
     M = _host()
     with pytest.raises(VitkError):
-        M.Mixup(mode='elem')
+        M.Mixup(mode='half')
     with pytest.raises(AssertionError):
         M.Mixup()(torch.zeros(3, 3, 8, 8), torch.zeros(3, dtype=torch.long))
 
@@ -90,6 +123,27 @@ def test_device_mixup_bit_exact(device, mix, cut, shape):
         assert torch.equal(got_t.cpu(), want_t), (it, lam, box)
         kinds.add(box is not None)
     assert kinds == ({True, False} if (mix > 0 and cut > 0) else {cut > 0})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["elem", "pair"])
+@pytest.mark.parametrize("mix,cut,shape", [(0.8, 1.0, (8, 3, 224, 224)), (0.8, 0.0, (4, 3, 32, 32)), (0.0, 1.0, (6, 3, 64, 48)),
+                                           (0.8, 1.0, (2, 1, 16, 18))])
+def test_device_mixup_per_sample_modes_bit_exact(device, mode, mix, cut, shape):
+    """modes 'elem' and 'pair' on the device, in place, against the oracle's loops over a clone of the batch"""
+    M = _host()
+    C = 1000 if shape[-1] == 224 else 10
+    m = M.Mixup(mixup_alpha=mix, cutmix_alpha=cut, prob=0.8, switch_prob=0.5, mode=mode, label_smoothing=0.1, num_classes=C)
+    g = torch.Generator().manual_seed(shape[0] * 11 + shape[-1])
+    for it in range(6):
+        x = torch.randn(*shape, generator=g)
+        y = torch.randint(0, C, (shape[0],), generator=g)
+        np.random.seed(2000 + it)
+        want_x, want_t, _ = RM.mix_per_sample(x, y, mode, mix, cut, 0.8, 0.5, C, 0.1)
+        np.random.seed(2000 + it)
+        got_x, got_t = m(x.to(device), y.to(device))
+        assert torch.equal(got_x.cpu(), want_x), (mode, it)
+        assert torch.equal(got_t.cpu(), want_t), (mode, it)
 
 
 @pytest.mark.gpu

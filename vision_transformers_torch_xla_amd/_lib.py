@@ -75,6 +75,8 @@ SIGNATURES = {
     "vitk_mixup_batch": (_i, [_p, _i, _i64, _f, _f, _p]),
     "vitk_cutmix_batch": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vitk_mixup_targets": (_i, [_p, _p, _i, _i, _i, _f, _f, _f, _f, _p]),
+    "vitk_mixup_elem": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "vitk_mixup_targets_elem": (_i, [_p, _p, _i, _i, _i, _p, _f, _f, _p]),
     "vitk_xent_label_fwd_bwd": (_i, [_p, _i, _p, _f, _p, _p, _i, _f, _i, _i, _p]),
     "vitk_xent_soft_fwd_bwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _f, _i, _i, _p]),
     "vitk_kd_kl_fwd_bwd": (_i, [_p, _i, _p, _i, _f, _p, _p, _i, _f, _i, _i, _p]),

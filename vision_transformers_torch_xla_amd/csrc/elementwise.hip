@@ -308,6 +308,54 @@ __global__ void mixup_targets_kernel(const int64_t* __restrict__ target, float* 
     }
 }
 
+// timm.data.Mixup in 'elem' and 'pair' mode (Mixup._mix_elem / _mix_pair; the reference forwards --mixup_mode, main.py:229, 628):
+// every sample (elem) or every pair (pair) has its own lambda, kind and box.  timm mixes sample i with the ORIGINAL of sample
+// j = B-1-i (it keeps a clone of the batch); here one thread holds the originals of both samples of a pair in registers and
+// writes both, so the batch is mixed in place without a copy.  Per sample: kind 0 = untouched (lambda = 1), 1 = mixup
+// (x_i*lam + x_j*(1-lam), products rounded first), 2 = cutmix (the box comes from x_j).
+__global__ void mixup_elem_kernel(float* __restrict__ x, int half, int B, int H, int W, size_t per4,
+                                  const vitk_mixup_sample* __restrict__ prm) {
+#pragma clang fp contract(off)
+    const size_t total = (size_t)half * per4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per4, e = i - b * per4;
+        const vitk_mixup_sample pa_ = prm[b], pc_ = prm[B - 1 - b];
+        if (pa_.kind == 0 && pc_.kind == 0) continue;
+        float4* pa = reinterpret_cast<float4*>(x) + b * per4 + e;
+        float4* pc = reinterpret_cast<float4*>(x) + (size_t)(B - 1 - b) * per4 + e;
+        const float4 a4 = *pa, c4 = *pc;
+        const float a[4] = {a4.x, a4.y, a4.z, a4.w}, c[4] = {c4.x, c4.y, c4.z, c4.w};
+        float na[4], nc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t idx = e * 4 + k;                 // element index inside the sample [C, H, W]
+            const int xx = (int)(idx % W), yy = (int)((idx / W) % H);
+            auto mixed = [&](const vitk_mixup_sample& p, float own, float other) {
+                if (p.kind == 1) return own * p.lam + other * p.one_minus_lam;
+                if (p.kind == 2 && yy >= p.yl && yy < p.yh && xx >= p.xl && xx < p.xh) return other;
+                return own;
+            };
+            na[k] = mixed(pa_, a[k], c[k]);
+            nc[k] = mixed(pc_, c[k], a[k]);
+        }
+        *pa = make_float4(na[0], na[1], na[2], na[3]);
+        *pc = make_float4(nc[0], nc[1], nc[2], nc[3]);
+    }
+}
+
+// timm mixup_target with one lambda per sample (a [B,1] tensor): y1 * lam_b + y2 * (1 - lam_b), the difference formed in fp32
+__global__ void mixup_targets_elem_kernel(const int64_t* __restrict__ target, float* __restrict__ out, int ldo, int B, int C,
+                                          const float* __restrict__ lam_rows, float on, float off) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.x;
+    const int64_t t1 = target[b], t2 = target[B - 1 - b];
+    const float lam = lam_rows[b], oml = 1.0f - lam;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float v1 = (c == t1) ? on : off, v2 = (c == t2) ? on : off;
+        out[(size_t)b * ldo + c] = v1 * lam + v2 * oml;
+    }
+}
+
 // dst[list[i]] = src[list[i]] for whole samples of `per8` 16-byte pieces each: the samples that skip a residual branch under
 // stochastic depth keep their activations (x + 0 * branch(x), timm DropPath as used at models/vision_transformer.py:176-177)
 __global__ void copy_samples_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int* __restrict__ list, int count,
@@ -490,6 +538,31 @@ int vitk_mixup_targets(const int64_t* target, float* out, int ldo, int B, int C,
     VITK_REQUIRE(target && out && B > 0 && C > 0 && ldo >= C, "mixup_targets: bad arguments");
     mixup_targets_kernel<<<B, 256, 0, (hipStream_t)stream>>>(target, out, ldo, B, C, lam, one_minus_lam, on_value, off_value);
     return vitk_check_launch("mixup_targets");
+}
+
+int vitk_mixup_elem(float* x, int B, int C, int H, int W, const vitk_mixup_sample* params_host, const vitk_mixup_sample* params_dev,
+                    void* stream) {
+    VITK_REQUIRE(x && params_host && params_dev && B > 0 && C > 0 && H > 0 && W > 0, "mixup_elem: bad arguments");
+    VITK_REQUIRE(B % 2 == 0, "mixup_elem: batch size should be even when using this (B=%d)", B);
+    const int64_t per_sample = (int64_t)C * H * W;
+    VITK_REQUIRE(per_sample % 4 == 0 && vitk_aligned(x, 16) && vitk_aligned(params_dev, 4),
+                 "mixup_elem: elements per sample must be a multiple of 4, x 16-byte aligned");
+    for (int b = 0; b < B; ++b) {
+        const vitk_mixup_sample& p = params_host[b];
+        VITK_REQUIRE(p.kind >= 0 && p.kind <= 2, "mixup_elem: sample %d: kind %d is not 0 (none), 1 (mixup) or 2 (cutmix)", b, p.kind);
+        VITK_REQUIRE(p.kind != 2 || (0 <= p.yl && p.yl <= p.yh && p.yh <= H && 0 <= p.xl && p.xl <= p.xh && p.xh <= W),
+                     "mixup_elem: sample %d: box [%d,%d)x[%d,%d) outside %dx%d", b, p.yl, p.yh, p.xl, p.xh, H, W);
+    }
+    const size_t per4 = (size_t)per_sample / 4;
+    mixup_elem_kernel<<<ew_grid((size_t)(B / 2) * per4), EW_BLOCK, 0, (hipStream_t)stream>>>(x, B / 2, B, H, W, per4, params_dev);
+    return vitk_check_launch("mixup_elem");
+}
+
+int vitk_mixup_targets_elem(const int64_t* target, float* out, int ldo, int B, int C, const float* lam_rows, float on_value,
+                            float off_value, void* stream) {
+    VITK_REQUIRE(target && out && lam_rows && B > 0 && C > 0 && ldo >= C, "mixup_targets_elem: bad arguments");
+    mixup_targets_elem_kernel<<<B, 256, 0, (hipStream_t)stream>>>(target, out, ldo, B, C, lam_rows, on_value, off_value);
+    return vitk_check_launch("mixup_targets_elem");
 }
 
 int vitk_copy_samples(const void* src, void* dst, const int* sample_list, int count, int64_t elems_per_sample, void* stream) {

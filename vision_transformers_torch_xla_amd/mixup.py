@@ -6,7 +6,11 @@ pixel and label arithmetic on the GPU (libvitk) instead of on the host before th
 Host side (this file): the per-batch random draws, in timm's order and from numpy's global generator like timm
 (np.random.rand for mix_prob, np.random.rand for switch_prob, np.random.beta for lambda, np.random.randint for the box
 centre), so a run seeded with np.random.seed(s) draws the same lambdas and boxes.  Device side: vitk_mixup_batch,
-vitk_cutmix_batch, vitk_mixup_targets.  Only mode='batch' (the reference's default, main.py:229) is implemented.
+vitk_cutmix_batch, vitk_mixup_targets for mode='batch' (the reference's default, main.py:229); vitk_mixup_elem and
+vitk_mixup_targets_elem for 'elem' (one lambda / kind / box per sample) and 'pair' (one per pair of samples).
+
+Scalar types follow the numpy the reference pins (1.26.4, requirements.txt:13): there `1 - lam` and `img_h * ratio` with a
+float32 lambda are float64 (both operands scalars), so the box sizes of the per-sample modes are derived in double here too.
 """
 from __future__ import annotations
 
@@ -69,8 +73,8 @@ class Mixup:
         self.switch_prob = switch_prob
         self.label_smoothing = label_smoothing
         self.num_classes = num_classes
-        if mode != 'batch':
-            raise VitkError(f"Mixup mode {mode!r} is not implemented (only 'batch', the reference's default)")
+        if mode not in ('batch', 'elem', 'pair'):
+            raise VitkError(f"Mixup mode {mode!r} is not one of 'batch', 'elem', 'pair'")
         self.mode = mode
         self.correct_lam = correct_lam
         self.mixup_enabled = True       # set to False to disable mixing (intended to be set by the train loop)
@@ -93,6 +97,49 @@ class Mixup:
             lam = float(lam_mix)
         return lam, use_cutmix
 
+    def _params_per_elem(self, batch_size):
+        """timm Mixup._params_per_elem: vectorised draws - switch coins, BOTH beta vectors (np.where evaluates its two branches),
+        then the mix_prob coins"""
+        lam = np.ones(batch_size, dtype=np.float32)
+        use_cutmix = np.zeros(batch_size, dtype=bool)
+        if self.mixup_enabled:
+            if self.mixup_alpha > 0. and self.cutmix_alpha > 0.:
+                use_cutmix = np.random.rand(batch_size) < self.switch_prob
+                lam_mix = np.where(use_cutmix, np.random.beta(self.cutmix_alpha, self.cutmix_alpha, size=batch_size),
+                                   np.random.beta(self.mixup_alpha, self.mixup_alpha, size=batch_size))
+            elif self.mixup_alpha > 0.:
+                lam_mix = np.random.beta(self.mixup_alpha, self.mixup_alpha, size=batch_size)
+            elif self.cutmix_alpha > 0.:
+                use_cutmix = np.ones(batch_size, dtype=bool)
+                lam_mix = np.random.beta(self.cutmix_alpha, self.cutmix_alpha, size=batch_size)
+            else:
+                assert False, "One of mixup_alpha > 0., cutmix_alpha > 0., cutmix_minmax not None should be true."
+            lam = np.where(np.random.rand(batch_size) < self.mix_prob, lam_mix.astype(np.float32), lam)
+        return lam, use_cutmix
+
+    def _sample_plan(self, shape):
+        """Host side of Mixup._mix_elem / _mix_pair: (MIXUP_SAMPLE records for vitk_mixup_elem, float32 lambda per sample for the
+        targets).  Boxes are drawn in sample order, one per cutmix sample (elem) or pair (pair), as timm's loops draw them."""
+        B = shape[0]
+        n = B if self.mode == 'elem' else B // 2
+        lam_batch, use_cutmix = self._params_per_elem(n)
+        prm = np.zeros(B, dtype=ops.MIXUP_SAMPLE)
+        for i in range(n):
+            lam = lam_batch[i]
+            if lam == 1.:
+                continue
+            if use_cutmix[i]:
+                (yl, yh, xl, xh), lam = cutmix_bbox_and_lam(shape[1:], float(lam), ratio_minmax=self.cutmix_minmax, correct_lam=self.correct_lam)
+                prm[i] = (2, 0., 0., int(yl), int(yh), int(xl), int(xh), 0)
+                lam_batch[i] = lam
+            else:
+                prm[i] = (1, lam, np.float32(1. - float(lam)), 0, 0, 0, 0, 0)
+            if self.mode == 'pair':
+                prm[B - 1 - i] = prm[i]
+        if self.mode == 'pair':
+            lam_batch = np.concatenate((lam_batch, lam_batch[::-1]))
+        return prm, lam_batch.astype(np.float32)
+
     def _mix_batch(self, x):
         lam, use_cutmix = self._params_per_batch()
         if lam == 1.:
@@ -112,8 +159,14 @@ class Mixup:
             target = target.cuda(non_blocking=True)
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
-        lam = self._mix_batch(x)
         off_value = self.label_smoothing / self.num_classes
         on_value = 1. - self.label_smoothing + off_value
+        if self.mode != 'batch':
+            prm, lam_rows = self._sample_plan(x.shape)
+            if prm["kind"].any():
+                ops.mixup_elem_(x, prm)
+            lam_dev = torch.from_numpy(lam_rows).to(x.device, non_blocking=True)
+            return x, ops.mixup_targets_elem(target.long().contiguous(), self.num_classes, lam_dev, on_value, off_value)
+        lam = self._mix_batch(x)
         target = ops.mixup_targets(target.long().contiguous(), self.num_classes, lam, on_value, off_value)
         return x, target

@@ -521,6 +521,38 @@ def mixup_targets(target, num_classes: int, lam: float, on_value: float, off_val
     return out
 
 
+MIXUP_SAMPLE = np.dtype([("kind", "<i4"), ("lam", "<f4"), ("one_minus_lam", "<f4"), ("yl", "<i4"), ("yh", "<i4"), ("xl", "<i4"), ("xh", "<i4"),
+                         ("reserved", "<i4")])      # struct vitk_mixup_sample
+
+
+def mixup_elem_(x, params, params_dev=None):
+    """in place on an fp32 [B,C,H,W] batch: sample b mixed with the original of sample B-1-b as params[b] says (MIXUP_SAMPLE
+    records: kind 0 none / 1 mixup / 2 cutmix, lam, one_minus_lam, box) - timm's Mixup modes 'elem' and 'pair'"""
+    _chk(x, f32, "x")
+    if x.dim() != 4:
+        raise _lib.VitkError(f"x: expected [B, C, H, W], got {tuple(x.shape)}")
+    B, Cc, Hh, Ww = x.shape
+    if params.dtype != MIXUP_SAMPLE or params.shape != (B,) or not params.flags.c_contiguous:
+        raise _lib.VitkError(f"params: expected {B} contiguous MIXUP_SAMPLE records")
+    if params_dev is None:
+        params_dev = torch.from_numpy(params.view(np.uint8).reshape(-1).copy()).to(x.device)
+    check(_lib.load().vitk_mixup_elem(_ptr(x), B, Cc, Hh, Ww, params.ctypes.data, _ptr(params_dev), _stream()), "mixup_elem")
+    return x
+
+
+def mixup_targets_elem(target, num_classes: int, lam_rows, on_value: float, off_value: float):
+    """int64 labels [B] + one lambda per sample (fp32 [B] on the device) -> soft targets fp32 [B, num_classes]"""
+    _chk(target, torch.int64, "target")
+    _chk(lam_rows, f32, "lam_rows")
+    B = target.shape[0]
+    if lam_rows.numel() != B:
+        raise _lib.VitkError(f"lam_rows: expected {B} values, got {lam_rows.numel()}")
+    out = torch.empty((B, num_classes), dtype=f32, device=target.device)
+    check(_lib.load().vitk_mixup_targets_elem(_ptr(target), _ptr(out), num_classes, B, num_classes, _ptr(lam_rows), float(on_value),
+                                              float(off_value), _stream()), "mixup_targets_elem")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ input pipeline tail
 def preprocess_images(src, flip=None, out=None, window=None, value_range=(0.0, 1.0), mean=None, std=None, patch=None):
     """src uint8 / fp32 [B, Hs, Ws, 3] on the GPU -> fp32 NCHW [B, 3, H, W]: flip_lr for flip[b] != 0 (uint8 [B]), value_range,
