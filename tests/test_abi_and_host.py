@@ -244,3 +244,41 @@ def test_metric_logger_semantics():
         ml.update(loss="high")
     top1, top5 = utils.accuracy(torch.tensor([[0.1, 0.9, 0.0, 0.2, 0.3, 0.4, 0.5], [0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.0]]), torch.tensor([1, 6]), (1, 5))
     assert top1.item() == 50.0 and top5.item() == 50.0
+
+
+def test_init_distributions_follow_the_reference_rules():
+    """The constructor's initialisation, as numbers (vision_transformer.py:634-648 init_weights with mode '', :998-1010
+    init_weights_vit_timm; deit.py:49-51): every Linear weight and pos_embed ~ N(0, 0.02) truncated at +-2 (absolute, i.e. never
+    reached), biases zero, LayerNorm at (1, 0), cls_token ~ N(0, 1e-6), dist_token like pos_embed, the patch convolution with
+    torch's Conv2d default (uniform within +-1/sqrt(fan_in) for weight and bias)."""
+    from vision_transformers_torch_xla_amd.vit import create_model
+    torch.manual_seed(0)
+    m = create_model("deit_small_distilled_patch16_224", num_classes=1000)
+    sd = dict(m.named_parameters())
+    for name, p in sd.items():
+        p = p.detach().double()
+        if name.endswith(".weight") and p.dim() == 2:                                 # every Linear, heads included
+            assert abs(p.mean().item()) < 4 * 0.02 / p.numel() ** 0.5 + 1e-6, name
+            assert abs(p.std().item() - 0.02) < 0.02 * 0.02, name
+            assert p.abs().max().item() < 0.02 * 6.5, name
+            # a normal sample, not a uniform one: the excess kurtosis of N is 0, of U it is -1.2
+            kurt = ((p - p.mean()) ** 4).mean().item() / p.var().item() ** 2 - 3.0
+            assert abs(kurt) < 0.15, (name, kurt)
+        elif "norm" in name and name.endswith(".weight"):
+            assert torch.equal(p, torch.ones_like(p)), name
+        elif name.endswith(".bias") and not name.startswith("patch_embed"):
+            assert torch.equal(p, torch.zeros_like(p)), name
+    for name in ("pos_embed", "dist_token"):
+        p = sd[name].detach().double()
+        assert abs(p.std().item() - 0.02) < 0.02 * 0.1 and p.abs().max().item() < 0.13, name
+    cls = sd["cls_token"].detach().double()
+    assert 0 < cls.abs().max().item() < 1e-5 and abs(cls.std().item() - 1e-6) < 3e-7
+    w, b = sd["patch_embed.proj.weight"].detach().double(), sd["patch_embed.proj.bias"].detach().double()
+    bound = 1.0 / (3 * 16 * 16) ** 0.5
+    assert w.shape == (384, 3, 16, 16) and w.abs().max().item() <= bound and b.abs().max().item() <= bound
+    assert abs(w.std().item() - bound / 3 ** 0.5) < 0.01 * bound          # uniform(-bound, bound): std = bound / sqrt(3)
+    kurt = (w ** 4).mean().item() / w.var().item() ** 2 - 3.0
+    assert abs(kurt + 1.2) < 0.05
+    # stochastic-depth rates: linspace(0, rate, depth) over the blocks (vision_transformer.py:580)
+    m2 = create_model("vit_small_patch16_224", drop_path_rate=0.1)
+    assert np.allclose([blk.drop_path for blk in m2.blocks], np.linspace(0, 0.1, 12))

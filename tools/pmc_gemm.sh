@@ -1,7 +1,7 @@
 #!/bin/bash
 # Matrix-pipe / wait counters of the GEMM kernels, per epilogue instantiation, over tools/bench_gemm.py (each shape of the
 # ViT-B step a few times).  Two counter passes in runs of their own.  usage (GPU box): bash tools/pmc_gemm.sh [tag]
-#   afterwards: python tools/summarize_pmc_gemm.py gpurun_out/<tag> profiles/r2_pmc_gemm.md
+#   afterwards: python tools/summarize_pmc_gemm.py gpurun_out/<tag> profiles/r3_pmc_gemm.md
 tag=${1:-pmc_gemm}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out

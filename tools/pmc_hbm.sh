@@ -2,7 +2,7 @@
 # HBM-side traffic of every kernel of bench.py's step: two counter passes (their own runs, counters only), then the summary
 # that bench.py's roofline.traffic reads.  usage (on the GPU box): bash tools/pmc_hbm.sh [tag]
 #   -> gpurun_out/<tag>/{f,w}/..._counter_collection.csv ; afterwards, here:
-#   python tools/summarize_pmc_hbm.py gpurun_out/<tag> profiles/r2_pmc_hbm.md tools/pmc_hbm.json
+#   python tools/summarize_pmc_hbm.py gpurun_out/<tag> profiles/r3_pmc_hbm.md tools/pmc_hbm.json
 tag=${1:-pmc_hbm}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out

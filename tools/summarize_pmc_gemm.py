@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-instantiation SQ counters of the GEMM kernels from the counter passes of tools/pmc_gemm.sh.
 
-usage: python tools/summarize_pmc_gemm.py gpurun_out/pmc_gemm profiles/r2_pmc_gemm.md
+usage: python tools/summarize_pmc_gemm.py gpurun_out/pmc_gemm profiles/r3_pmc_gemm.md
 
 Every launch of tools/bench_gemm.py is one shape of the ViT-B/16 step (512 images); launches are keyed by kernel
 instantiation and grid-independent shape order, counters are averaged per launch.  SQ cycle counters are summed over all

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM-side bytes per launch and kernel family from the two counter passes of tools/pmc_hbm.sh.
 
-usage: python tools/summarize_pmc_hbm.py gpurun_out/pmc_hbm profiles/r2_pmc_hbm.md tools/pmc_hbm.json
+usage: python tools/summarize_pmc_hbm.py gpurun_out/pmc_hbm profiles/r3_pmc_hbm.md tools/pmc_hbm.json
 
 Counter unit: KB.  On gfx950 FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane streaming reads at 64 bytes, so
 fetch bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact for 16-byte-per-lane stores (MI355X_MICROARCH.md, HBM / rocprofv3
