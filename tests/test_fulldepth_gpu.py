@@ -7,8 +7,8 @@ against BOTH oracles on identical weights, inputs and stochastic-depth draws (dr
   * the fp32 oracle (exact math, the reference's CPU semantics): the distance that matters, and the one that cannot move
     with the kernels - every number measured against it is pinned in tests/golden/fp32_distance.json (tests/util.py).
 
-Besides the end results the residual stream is compared block by block (the oracle's `taps`), which is the drift table
-of DESIGN.md: the relative distance grows like the square root of the number of rounded stages and stays at the bf16
+Besides the end results the residual stream is compared block by block (the oracle's `taps`) and written out as a drift
+table (VITK_DRIFT_DIR): the relative distance grows like the square root of the number of rounded stages and stays at the bf16
 quantisation floor at depth 12 and 24.  The bars below are a few times the measured values; the recorded values
 themselves are held to 1.25 x by the anchor file."""
 import copy
@@ -23,7 +23,8 @@ from tests.util import fp32_anchor, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-# measured: residual stream <= 6e-3 at block 24, logits <= 8e-3, whole gradient <= 1.2e-2 (drift table)
+# measured against the fp32 oracle on MI355X: residual stream 1.05e-2 after block 12 (ViT-B) and 1.4e-2 after block 24 (ViT-L),
+# logits <= 1.1e-2, whole gradient <= 1.9e-2, cosine >= 0.99982
 STREAM_TOL = 2e-2
 LOGIT_TOL = 2.5e-2
 GRAD_TOL = 4e-2

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 kernel tables: rocprofv3 kernel trace of bench.py (ViT-B/16 224) and of the ViT-L/16, 384-px and distillation workloads,
+# Kernel tables of all headline workloads: rocprofv3 kernel trace of bench.py (ViT-B/16 224) and of the ViT-L/16, 384-px and distillation workloads,
 # then every workload once without the profiler.  Per-kernel durations are only meaningful when launches do not share the chip,
 # so the weight-gradient side stream is off in the profiled runs (bench.py does the same in its event-bracketed steps).
 set -o pipefail
