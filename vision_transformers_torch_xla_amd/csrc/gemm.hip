@@ -151,7 +151,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTParams p) {
 #define NTP_DRAIN 16                 // output stores a wave issues per full tile, at least (16 row groups, one each)
 #define NTP_LDS (4 * LTILE * 2 + 8 * 16 * 64 * 4)   // bytes: operand image + 4 KB of epilogue staging per wave
 
-template <int EPI>
+// GMAP (bias + residual epilogue only): the stochastic-depth tables are looked up per ROW inside the store loop - for samples
+// of fewer than 128 rows, or tables with different group sizes.  It is an instantiation of its own because a load under a
+// run-time condition inside that loop makes hipcc wait for EVERY outstanding memory operation (s_waitcnt vmcnt(0)) where the
+// two paths join, also on the path that loaded nothing: 75 such waits per tile instead of 9 in the common instantiation
+// (2-4 % of a bias + residual launch).
+template <int EPI, bool GMAP = false>
 __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t lsm[];   // [2 buffers][A tile | B tile], [8 waves][16][64] fp32
 
@@ -351,46 +356,54 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
         // stream and are scaled by rowscale[.].  A wave's 128 rows span at most two samples when a sample has >= 128 rows: the two
         // samples' row offsets and scales are looked up ONCE per tile (wave-uniform), and a row picks between them with one
         // compare - instead of two integer divisions and two dependent loads in front of every side fetch and every store.
-        bool fastmap = false;
-        int map_bnd = 0, map_off0 = 0, map_off1 = 0;
+        constexpr bool fastmap = EPI == VITK_EPI_BIAS_RES && !GMAP;      // without tables: one "sample" that never ends, offset 0, scale 1
+        int map_bnd = 0x7fffffff, map_off0 = 0, map_off1 = 0;
         float map_rs0 = 1.0f, map_rs1 = 1.0f;
         if (EPI == VITK_EPI_BIAS_RES && (p.smap != nullptr || p.rowscale != nullptr)) {
             const int per = p.smap != nullptr ? p.rps : p.rows_per_group;
-            fastmap = per >= 128 && (p.smap == nullptr || p.rowscale == nullptr || p.rps == p.rows_per_group);
             if (fastmap) {
                 int mw = __builtin_amdgcn_readfirstlane(m0) + wm * 128;
                 mw = mw < p.M ? mw : p.M - 1;
                 const int c0 = mw / per;
                 map_bnd = (c0 + 1) * per;
                 const int c1 = map_bnd < p.M ? c0 + 1 : c0;
+                // The tables are read through the scalar cache (constant address space, wave-uniform index): a vector load here
+                // would be waited for with vmcnt, which counts in issue order - i.e. together with the next tile's operand
+                // requests issued a moment ago, a full memory round trip in front of every epilogue.  Nothing in this kernel
+                // writes the tables.
+                typedef const __attribute__((address_space(4))) int* ktab_i;
+                typedef const __attribute__((address_space(4))) float* ktab_f;
                 if (p.smap != nullptr) {
-                    map_off0 = __builtin_amdgcn_readfirstlane((p.smap[c0] - c0) * per);
-                    map_off1 = __builtin_amdgcn_readfirstlane((p.smap[c1] - (c0 + 1)) * per);
+                    const ktab_i sm = (ktab_i)p.smap;
+                    map_off0 = (sm[c0] - c0) * per;
+                    map_off1 = (sm[c1] - (c0 + 1)) * per;
                 }
                 if (p.rowscale != nullptr) {
-                    map_rs0 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.rowscale[c0])));
-                    map_rs1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.rowscale[c1])));
+                    const ktab_f rsc = (ktab_f)p.rowscale;
+                    map_rs0 = rsc[c0];
+                    map_rs1 = rsc[c1];
                 }
             }
         }
         u32x4 side[SIDE ? 8 : 1];
-        auto fetch_side = [&](int tm_base) {
+        // the two pieces (16 rows) of row group tm, into the ring slots of tm & 3
+        auto fetch_side = [&](int tm) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int m = m0 + wm * 128 + (tm_base + (i >> 1)) * 16 + (i & 1) * 8 + srow;
+            for (int i = 0; i < 2; ++i) {
+                int m = m0 + wm * 128 + tm * 16 + i * 8 + srow;
                 m = m < p.M ? m : p.M - 1;
-                if (EPI == VITK_EPI_BIAS_RES && p.smap != nullptr) {
+                if (EPI == VITK_EPI_BIAS_RES) {
                     if (fastmap) m += m >= map_bnd ? map_off1 : map_off0;
-                    else { const int c = m / p.rps; m = p.smap[c] * p.rps + (m - c * p.rps); }
+                    else if (p.smap != nullptr) { const int c = m / p.rps; m = p.smap[c] * p.rps + (m - c * p.rps); }
                 }
                 const int n = ecol < p.N ? ecol : 0;
-                side[SIDE ? i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(nt_side_ptr<EPI>(p, m, n)));
+                side[SIDE ? (tm & 3) * 2 + i : 0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(nt_side_ptr<EPI>(p, m, n)));
             }
         };
-        if (SIDE) fetch_side(0);
         // the bias depends on the lane's columns only: one fetch per tile (behind the stores hipcc would re-load it 16 times)
         constexpr bool BIAS = EPI != VITK_EPI_PLAIN && EPI != VITK_EPI_DGELU && EPI != VITK_EPI_MUL;
         float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (SIDE) { fetch_side(0); fetch_side(1); fetch_side(2); fetch_side(3); }
         if (BIAS) add_f32<8>(p.bias + (ecol < p.N ? ecol : 0), bias8);
 #pragma unroll
         for (int tm = 0; tm < 8; ++tm) {
@@ -398,7 +411,7 @@ __global__ __launch_bounds__(512) void gemm_ntp_kernel(const GemmNTParams p) {
             if (SIDE) {
                 unpack_bf16x8(side[(tm & 3) * 2], sv[0]);
                 unpack_bf16x8(side[(tm & 3) * 2 + 1], sv[1]);
-                if (tm == 3) { asm volatile("" ::: "memory"); fetch_side(4); }
+                if (tm == 3) { asm volatile("" ::: "memory"); fetch_side(4); fetch_side(5); fetch_side(6); fetch_side(7); }
             }
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
@@ -1099,6 +1112,22 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
         }                                                                                                               \
         gemm_ntp_kernel<E><<<grid, 512, smem, s>>>(p);                                                         \
     } break;
+        // bias + residual with stochastic-depth tables the per-tile lookup cannot take (see gemm_ntp_kernel): the per-row instantiation
+        bool per_row_tables = false;
+        if (epilogue == VITK_EPI_BIAS_RES && (p.smap != nullptr || p.rowscale != nullptr)) {
+            const int per = p.smap != nullptr ? p.rps : p.rows_per_group;
+            per_row_tables = !(per >= 128 && (p.smap == nullptr || p.rowscale == nullptr || p.rps == p.rows_per_group));
+        }
+        if (per_row_tables) {
+            static VitkLdsOnce once = {};
+            if (int rc_ = vitk_lds_once(once, (const void*)gemm_ntp_kernel<VITK_EPI_BIAS_RES, true>, smem, "gemm_nt")) {
+                if (pr) vitk_prof_end(stream);
+                return rc_;
+            }
+            gemm_ntp_kernel<VITK_EPI_BIAS_RES, true><<<grid, 512, smem, s>>>(p);
+            if (pr) vitk_prof_end(stream);
+            return vitk_check_launch("gemm_nt");
+        }
         switch (epilogue) {
             VITK_LAUNCH_BIG(VITK_EPI_PLAIN)
             VITK_LAUNCH_BIG(VITK_EPI_BIAS)
