@@ -93,6 +93,28 @@ def test_per_sample_host_plan_matches_oracle(mode, mix, cut):
         assert torch.allclose(want_t.sum(1), torch.ones(B), atol=1e-6)
 
 
+def test_per_sample_entry_point_validates_on_the_host():
+    """vitk_mixup_elem refuses bad plans before anything is launched (no GPU needed to see that)"""
+    import ctypes
+    from vision_transformers_torch_xla_amd import _lib, ops
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(8192)
+    addr = (ctypes.addressof(buf) + 15) // 16 * 16
+    prm = np.zeros(4, dtype=ops.MIXUP_SAMPLE)
+    assert prm.itemsize == 32                                         # struct vitk_mixup_sample
+
+    def call(plan, B=4, C=3, H=8, W=8):
+        return lib.vitk_mixup_elem(addr, B, C, H, W, plan.ctypes.data, addr, None)
+    odd = np.zeros(3, dtype=ops.MIXUP_SAMPLE)
+    assert call(odd, B=3) != 0 and b"even" in lib.vitk_last_error()
+    bad = prm.copy(); bad[1]["kind"] = 3
+    assert call(bad) != 0 and b"kind" in lib.vitk_last_error()
+    box = prm.copy(); box[2] = (2, 0., 0., 0, 9, 0, 4, 0)            # rows [0, 9) of an 8-row image
+    assert call(box) != 0 and b"outside" in lib.vitk_last_error()
+    assert call(prm, C=1, H=3, W=3) != 0 and b"multiple of 4" in lib.vitk_last_error()
+    assert lib.vitk_mixup_targets_elem(None, addr, 10, 4, 10, addr, 0.9, 0.01, None) != 0
+
+
 def test_rejects_other_modes_and_odd_batches():
     from vision_transformers_torch_xla_amd._lib import VitkError
     M = _host()

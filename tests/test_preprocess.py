@@ -41,6 +41,23 @@ def test_abi_rejects_bad_windows_before_launch():
     assert lib.vitk_preprocess_images(p16, 1, None, p16, 1, 8, 8, 8, 8, 0, 0, 0.0, 1.0, m, None, None) == -22
 
 
+def test_patch_matrix_entry_points_validate_on_the_host():
+    from vision_transformers_torch_xla_amd import _lib as L
+    lib = L.load()
+    buf = ctypes.create_string_buffer(4096)
+    p16 = (ctypes.cast(buf, ctypes.c_void_p).value + 15) // 16 * 16
+    # patch size: a multiple of 8 that divides the window
+    assert lib.vitk_preprocess_patches(p16, 1, None, p16, 12, 1, 24, 24, 24, 24, 0, 0, 0.0, 1.0, None, None, None) == -22
+    assert b"multiple of 8" in lib.vitk_last_error()
+    assert lib.vitk_preprocess_patches(p16, 1, None, p16, 16, 1, 24, 32, 24, 32, 0, 0, 0.0, 1.0, None, None, None) == -22
+    assert lib.vitk_preprocess_patches(p16, 1, None, p16, 8, 1, 16, 16, 16, 16, 1, 0, 0.0, 1.0, None, None, None) == -22
+    assert b"outside" in lib.vitk_last_error()
+    assert lib.vitk_preprocess_patches(None, 1, None, p16, 8, 1, 16, 16, 16, 16, 0, 0, 0.0, 1.0, None, None, None) == -22
+    assert lib.vitk_resample_patches(p16, 300, p16, p16, p16, 12, 1, 24, 0, 0.0, 1.0, None, None, None) == -22
+    assert b"multiple of 8" in lib.vitk_last_error()
+    assert lib.vitk_resample_patches(p16, 300, p16, p16, None, 8, 1, 24, 0, 0.0, 1.0, None, None, None) == -22
+
+
 def test_central_crop_window_matches_oracle():
     from vision_transformers_torch_xla_amd import data
     for h, w in ((256, 341), (256, 256), (300, 257), (224, 224)):
