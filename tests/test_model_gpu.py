@@ -335,7 +335,8 @@ def test_padded_heads_match_the_unpadded_kernels(device, name, hd, hp):
 
 
 @pytest.mark.parametrize("classes,pool,name", [(37, "avg", "vit_tiny_patch16_224"), (100, "token", "vit_tiny_patch16_224"),
-                                               (1, "avg", "vit_tiny_patch16_224"), (37, "token", "deit_tiny_distilled_patch16_224")])
+                                               (1, "avg", "vit_tiny_patch16_224"), (37, "token", "deit_tiny_distilled_patch16_224"),
+                                               (21843, "avg", "vit_tiny_patch16_224")])      # ImageNet-21k: wide and odd
 def test_class_counts_that_are_not_multiples_of_8(device, classes, pool, name):
     """--nb_classes is free in the reference (main.py:643-649; fine-tuning onto 37 or 100 classes is its stated use, :653-674).
     The head GEMMs run on zero-padded bf16 copies: logits, loss and every gradient against the oracle, the parameters keep
