@@ -380,9 +380,16 @@ def test_class_counts_that_are_not_multiples_of_8(device, classes, pool, name):
     optim_factory.create_optimizer(A, m).step()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in m.parameters())
+    m._forced_drop_scales = None                                      # the injected factors would apply in eval mode too
     with torch.no_grad():
         m.eval()
-        assert tuple(m(x.to(device)).shape) == (B, classes)           # the padded copies follow the optimizer step
+        after = m(x.to(device))
+        assert tuple(after.shape) == (B, classes)                     # the padded copies follow the optimizer step
+        # a weight EMA is a deep copy with padded copies of its own: with decay 0 it evaluates exactly like the model
+        from vision_transformers_torch_xla_amd.utils import ModelEma
+        ema = ModelEma(m, decay=0.0)
+        ema.update(m)
+        assert torch.equal(ema.ema(x.to(device)), after)
 
 
 def test_grad_accumulation_and_zero_grad(device):
