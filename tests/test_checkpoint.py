@@ -86,3 +86,38 @@ def test_finetune_from_1000_classes_onto_37(tmp_path):
     assert sorted(missing) == ["head.bias", "head.weight"] and unexpected == []
     assert torch.equal(dst.blocks[0].mlp.fc1.weight, src.blocks[0].mlp.fc1.weight)
     assert set(dst.state_dict()) == set(src.state_dict()) and dst.state_dict()["head.weight"].shape == (37, 192)
+
+
+def test_create_model_checkpoint_path_formats(tmp_path):
+    """create_model(checkpoint_path=...) as models/_factory.py:151-152 -> models/_helpers.py:44-140: a '.safetensors' file or a
+    torch file; EMA weights ('state_dict_ema', 'model_ema') before 'state_dict' before 'model' before the bare dict; 'module.' and
+    '_orig_mod.' prefixes stripped; strict; a missing file raises FileNotFoundError.  --finetune reads safetensors too."""
+    import pytest
+    torch.manual_seed(0)
+    src = create_model("vit_tiny_patch16_224", num_classes=16, global_pool="avg", depth=1)
+    sd = {k: v.detach().clone() for k, v in src.state_dict().items()}
+    other = {k: v + 1.0 for k, v in sd.items()}
+
+    def same(model, want):
+        return all(torch.equal(v, want[k]) for k, v in model.state_dict().items())
+    kw = dict(num_classes=16, global_pool="avg", depth=1)
+    utils.save_safetensors(src, tmp_path / "m.safetensors")
+    assert same(create_model("vit_tiny_patch16_224", checkpoint_path=str(tmp_path / "m.safetensors"), **kw), sd)
+    torch.save(sd, tmp_path / "bare.pth")
+    assert same(create_model("vit_tiny_patch16_224", checkpoint_path=str(tmp_path / "bare.pth"), **kw), sd)
+    torch.save({"model": sd, "model_ema": other, "epoch": 3}, tmp_path / "ema.pth")
+    assert same(create_model("vit_tiny_patch16_224", checkpoint_path=str(tmp_path / "ema.pth"), **kw), other)       # EMA weights first
+    assert all(torch.equal(v, sd[k]) for k, v in utils.load_checkpoint_state_dict(str(tmp_path / "ema.pth"), use_ema=False).items())
+    torch.save({"state_dict": {"module." + k: v for k, v in sd.items()}, "model": other}, tmp_path / "ddp.pth")
+    assert same(create_model("vit_tiny_patch16_224", checkpoint_path=str(tmp_path / "ddp.pth"), **kw), sd)          # 'state_dict' before 'model'
+    torch.save({"_orig_mod." + k: v for k, v in sd.items()}, tmp_path / "compiled.pth")
+    assert same(create_model("vit_tiny_patch16_224", checkpoint_path=str(tmp_path / "compiled.pth"), **kw), sd)
+    with pytest.raises(FileNotFoundError):
+        create_model("vit_tiny_patch16_224", checkpoint_path=str(tmp_path / "nothing.pth"), **kw)
+    with pytest.raises(RuntimeError):                                    # strict: another head size is an error on this path
+        create_model("vit_tiny_patch16_224", checkpoint_path=str(tmp_path / "bare.pth"), num_classes=24, global_pool="avg", depth=1)
+    # the fine-tune path reads the same file formats and drops the head instead
+    m = create_model("vit_tiny_patch16_224", num_classes=24, global_pool="avg", depth=1)
+    missing, unexpected = utils.load_finetune_checkpoint(m, str(tmp_path / "m.safetensors"))
+    assert sorted(missing) == ["head.bias", "head.weight"] and not unexpected
+    assert torch.equal(m.state_dict()["blocks.0.attn.qkv.weight"], sd["blocks.0.attn.qkv.weight"])

@@ -357,8 +357,46 @@ def _load_checkpoint_file(path):
     import argparse
     if str(path).startswith("http"):
         raise RuntimeError("checkpoint URLs cannot be fetched in this build (no network): pass a local file")
+    if str(path).endswith(".safetensors"):          # models/_helpers.py:62-65: a flat name -> tensor file, nothing to execute
+        import safetensors.torch
+        return safetensors.torch.load_file(str(path), device="cpu")
     with torch.serialization.safe_globals([argparse.Namespace]):
         return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def load_checkpoint_state_dict(checkpoint_path, use_ema=True):
+    """The state dict of a checkpoint file as models/_helpers.py:44-86 (load_state_dict) picks it: '.safetensors' or torch file;
+    'state_dict_ema' / 'model_ema' first when use_ema, then 'state_dict', then 'model', else the file's top level; the 'module.'
+    (DistributedDataParallel) and '_orig_mod.' (torch.compile) prefixes removed from the keys (:30-41).  A missing file raises
+    FileNotFoundError like the reference."""
+    if not (checkpoint_path and os.path.isfile(checkpoint_path)):
+        print("No checkpoint found at '{}'".format(checkpoint_path))
+        raise FileNotFoundError()
+    checkpoint = _load_checkpoint_file(checkpoint_path)
+    key = ""
+    if isinstance(checkpoint, dict):
+        if use_ema and checkpoint.get("state_dict_ema", None) is not None:
+            key = "state_dict_ema"
+        elif use_ema and checkpoint.get("model_ema", None) is not None:
+            key = "model_ema"
+        elif "state_dict" in checkpoint:
+            key = "state_dict"
+        elif "model" in checkpoint:
+            key = "model"
+    sd = checkpoint[key] if key else checkpoint
+    out = {}
+    for k, v in sd.items():
+        for pre in ("module.", "_orig_mod."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        out[k] = v
+    return out
+
+
+def save_safetensors(model, path):
+    """model.state_dict() (timm's keys and shapes) as a .safetensors file"""
+    import safetensors.torch
+    safetensors.torch.save_file({k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}, str(path))
 
 
 def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):

@@ -1032,11 +1032,7 @@ def create_model(model_name: str, pretrained: bool = False, pretrained_cfg=None,
     cfg = dict(_MODEL_CFGS[name])
     cfg.update(kwargs)
     model = VisionTransformer(patch_size=16, **cfg)
-    if checkpoint_path:
-        sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-        for key in ("model", "module", "state_dict"):
-            if isinstance(sd, dict) and key in sd:
-                sd = sd[key]
-                break
-        model.load_state_dict(sd)
+    if checkpoint_path:          # models/_factory.py:151-152 -> load_checkpoint (models/_helpers.py:89-140): strict, EMA weights first
+        from .utils import load_checkpoint_state_dict
+        model.load_state_dict(load_checkpoint_state_dict(checkpoint_path, use_ema=True))
     return model
