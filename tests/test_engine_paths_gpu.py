@@ -11,6 +11,7 @@ bit equality."""
 import argparse
 import copy
 
+import numpy as np
 import pytest
 import torch
 
@@ -580,3 +581,45 @@ def test_memorising_one_batch_follows_the_fp32_oracle(device):
         assert abs(g - w) <= (0.01 + 0.003 * i) * max(w, 0.2) + 0.01, (i, g, w)      # measured: <= 0.016 at every step
     assert want[-1] < 0.1 * want[0] and got[-1] < 0.1 * got[0]          # both memorised the batch
     assert stats["class_acc"] > 0.5                                     # averaged over the epoch: wrong at first, right at the end
+
+
+def test_loggers_receive_the_reference_records(device):
+    """log_writer.update(loss=, lr=) every step and wandb_logger._wandb.log({...}) at the console's frequency, with the reference's
+    keys and step numbering (engine.py:305-323); class accuracy only when mixup is off"""
+    from vision_transformers_torch_xla_amd import engine, optim_factory
+    from vision_transformers_torch_xla_amd.losses import LabelSmoothingCrossEntropy
+    from vision_transformers_torch_xla_amd.vit import create_model
+
+    class Writer:
+        def __init__(self):
+            self.calls, self.steps = [], []
+
+        def set_step(self, step=None):
+            self.steps.append(step)
+
+        def update(self, head="scalar", step=None, **kw):
+            self.calls.append(kw)
+
+    class Wandb:
+        class _W:
+            def __init__(self):
+                self.records = []
+
+            def log(self, d):
+                self.records.append(dict(d))
+
+        def __init__(self):
+            self._wandb = Wandb._W()
+    torch.manual_seed(0)
+    m = create_model("vit_tiny_patch16_224", num_classes=40, global_pool="avg", depth=1).to(device)
+    opt = optim_factory.create_optimizer(_Args, m)
+    data = [_batch(4, 224, 40, 900 + i) for i in range(8)]
+    writer, wb = Writer(), Wandb()
+    stats = engine.train_one_epoch(m, LabelSmoothingCrossEntropy(0.1), data, opt, device, 2, None, 0, None, None, log_writer=writer,
+                                   wandb_logger=wb, start_steps=100, num_training_steps_per_epoch=8, update_freq=1, log_freq=3)
+    assert writer.steps == [2 * 8 * 1] and len(writer.calls) == 8 and all(set(c) == {"loss", "lr"} for c in writer.calls)
+    recs = wb._wandb.records
+    assert [r["train/step"] for r in recs] == [100, 101, 102, 103, 104, 106]          # steps 0-4, then every third
+    assert all(set(r) == {"train/loss", "train/learning_rate", "train/epoch", "train/step", "train/accuracy"} for r in recs)
+    assert all(r["train/epoch"] == 2 and r["train/learning_rate"] == opt.param_groups[0]["lr"] and np.isfinite(r["train/loss"]) for r in recs)
+    assert np.isfinite(stats["loss"])

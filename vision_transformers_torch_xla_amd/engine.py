@@ -210,6 +210,14 @@ def train_one_epoch(model: torch.nn.Module, criterion: torch.nn.Module, data_loa
             if log_writer is not None:          # a per-step host log is the caller's choice: it costs one sync per step
                 lv = metric_logger.meters["loss"].value if metric_logger.meters["loss"].count else float("nan")
                 log_writer.update(loss=lv, lr=optimizer.param_groups[0]["lr"])
+            # the experiment tracker gets the same record at the console's frequency (engine.py:311-323): the keys and the
+            # step numbering of the reference; reading the scalars is the one host sync a caller who passes a logger asks for
+            if wandb_logger is not None and (data_iter_step % log_freq == 0 or data_iter_step < 5):
+                record = {"train/loss": float(loss.detach()), "train/learning_rate": optimizer.param_groups[0]["lr"], "train/epoch": epoch,
+                          "train/step": start_steps + data_iter_step if start_steps else data_iter_step}
+                if class_acc is not None:
+                    record["train/accuracy"] = float(class_acc)
+                wandb_logger._wandb.log(record)
 
     finally:
         if graphed is not None:       # also when the loop raises: the model must not keep reading the static DropPath table
