@@ -122,6 +122,8 @@ def test_rejects_other_modes_and_odd_batches():
         M.Mixup(mode='half')
     with pytest.raises(AssertionError):
         M.Mixup()(torch.zeros(3, 3, 8, 8), torch.zeros(3, dtype=torch.long))
+    with pytest.raises(VitkError, match="patch matrix"):              # what a loader with patch=16 yields is not an image batch
+        M.Mixup()(torch.zeros(4 * 196, 768, dtype=torch.bfloat16), torch.zeros(4, dtype=torch.long))
 
 
 @pytest.mark.gpu

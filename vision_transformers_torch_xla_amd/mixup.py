@@ -152,6 +152,9 @@ class Mixup:
         return lam
 
     def __call__(self, x, target):
+        if x.dim() != 4 or x.shape[0] != target.shape[0]:
+            raise VitkError(f"Mixup mixes image batches [B, C, H, W] with B labels; got samples {tuple(x.shape)} and {target.shape[0]} labels "
+                            f"(a loader's patch= option yields the model's patch matrix, which cannot be mixed: leave it off with Mixup)")
         assert len(x) % 2 == 0, 'Batch size should be even when using this'
         if not x.is_cuda:           # the loader's host batch: copy first, mix on the device
             x = x.cuda(non_blocking=True)
